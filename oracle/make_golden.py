@@ -1,0 +1,294 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the REAL reference.
+
+Runs only in the build container (needs /root/reference); never on the GPU box.
+It imports the reference's libs.modeling / libs.utils (recipe: SURVEY.md appendix A),
+loads the deterministic synthetic weights of oracle.ummaformer_ref.synth_state_dict into
+the reference model, runs it, checks the CPU oracle against it, and stores only inputs
+seeds + expected outputs (no reference source, no weights).
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+"""
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ummaformer_ref as R  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.modules["torchsort"] = types.ModuleType("torchsort")   # losses.py:3 imports, never uses
+    sys.modules["h5py"] = types.ModuleType("h5py")             # deepfake_video_audio.py:3 same
+    from oracle.build_ref import build_ref_nms
+    build_ref_nms()                                            # oracle/_ref/nms_1d_cpu*.so
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    from libs.core import load_config, config as C
+    from libs.modeling import make_meta_arch
+    return load_config, C, make_meta_arch
+
+
+def ref_model(load_config, C, make_meta_arch, yaml_name, cfg):
+    rc = load_config(f"{REF}/configs_train/{yaml_name}", defaults=copy.deepcopy(C.DEFAULTS))
+    m = rc["model"]
+    vdim = max(8, cfg["input_dim"] // 12)
+    m.update(video_input_dim=vdim, audio_input_dim=cfg["input_dim"] - vdim,
+             max_seq_len=cfg["max_seq_len"], embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"],
+             head_dim=cfg["head_dim"], n_head=cfg["n_head"])
+    model = make_meta_arch(rc["model_name"], **m)
+    return model, rc
+
+
+def synth_inputs(cfg, lens, seed):
+    rs = np.random.RandomState(seed)
+    B, C, T = len(lens), cfg["input_dim"], cfg["max_seq_len"]
+    x = np.zeros((B, C, T), dtype=np.float32)
+    for b, n in enumerate(lens):
+        x[b, :, :n] = rs.standard_normal((C, n)).astype(np.float32)
+    mask = (np.arange(T)[None, :] < np.asarray(lens)[:, None]).astype(np.float32)
+    return torch.from_numpy(x), torch.from_numpy(mask)[:, None, :]
+
+
+def ref_forward_heads(model, x, mask_f):
+    """Replays av_fd_no_recon.py:346-379 on pre-batched tensors (so B>1 works in eval)."""
+    mb = mask_f > 0
+    norm_inputs, reco, cls_scores = model.interpolator(x, mb)
+    feats, masks = model.backbone(x, norm_inputs, x, mb)
+    fpn_feats, fpn_masks = model.neck(feats, masks)
+    logits = [t.permute(0, 2, 1) for t in model.cls_head(fpn_feats, fpn_masks)]
+    offsets = [t.permute(0, 2, 1) for t in model.reg_head(fpn_feats, fpn_masks)]
+    return dict(logits=logits, offsets=offsets, cls_scores=cls_scores, feats=feats, fpn=fpn_feats,
+                masks=[m.squeeze(1) for m in fpn_masks])
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def match_segments(seg_a, sc_a, seg_b, sc_b):
+    """Order-insensitive comparison of two detection lists: near-tied scores (|d| ~ 1e-8) may
+    swap ranks between two fp32 implementations (the reference's own sort is unstable,
+    av_fd_no_recon.py:789), so each row of A is matched to its nearest row of B."""
+    if seg_a.shape[0] == 0:
+        return 0.0, 0.0, torch.zeros(0, dtype=torch.int64)
+    d = (seg_a[:, None, :] - seg_b[None, :, :]).abs().amax(-1) + (sc_a[:, None] - sc_b[None, :]).abs()
+    perm = d.argmin(dim=1)
+    assert perm.unique().numel() == perm.numel(), "segment lists do not match one-to-one"
+    return maxdiff(seg_a, seg_b[perm]), maxdiff(sc_a, sc_b[perm]), perm
+
+
+def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_levels=True):
+    load_config, C, make_meta_arch = ctx
+    model, _ = ref_model(load_config, C, make_meta_arch, "deepfake_exp10.yaml", cfg)
+    shapes = R.param_shapes(cfg)
+    ref_sd = model.state_dict()
+    assert set(shapes) == set(ref_sd), (set(shapes) ^ set(ref_sd))
+    for k in shapes:
+        assert tuple(ref_sd[k].shape) == tuple(shapes[k]), (k, ref_sd[k].shape, shapes[k])
+    sd = R.synth_state_dict(shapes, wseed, trained_like)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x, mask = synth_inputs(cfg, lens, xseed)
+    with torch.no_grad():
+        ref = ref_forward_heads(model, x, mask)
+        mine = R.model_forward(sd, cfg, x, mask)
+    dl = max(maxdiff(a, b) for a, b in zip(ref["logits"], mine["logits"]))
+    do = max(maxdiff(a, b) for a, b in zip(ref["offsets"], mine["offsets"]))
+    dc = maxdiff(ref["cls_scores"], mine["cls_scores"])
+    df = max(maxdiff(a, b) for a, b in zip(ref["fpn"], mine["fpn"]))
+    print(f"[{name}] oracle vs reference: logits {dl:.3e} offsets {do:.3e} cls {dc:.3e} fpn {df:.3e}")
+    assert dl < 2e-4 and do < 2e-4 and dc < 2e-4, "oracle restatement disagrees with the reference"
+    out = dict(
+        cfg_keys=np.array(sorted(cfg.keys())), lens=np.asarray(lens), wseed=wseed, xseed=xseed,
+        trained_like=int(trained_like),
+        logits=torch.cat(ref["logits"], 1).numpy(), offsets=torch.cat(ref["offsets"], 1).numpy(),
+        cls_scores=ref["cls_scores"].numpy(),
+        fpn_sum=np.array([float(f.double().sum()) for f in ref["fpn"]]),
+        fpn_abs=np.array([float(f.double().abs().sum()) for f in ref["fpn"]]),
+    )
+    # full eval path of the reference (B=1 per clip): forward -> decode -> C++ NMS -> seconds
+    segs_all, scores_all, n_all, vc_all, kept_all = [], [], [], [], []
+    for b, n in enumerate(lens):
+        clip = dict(video_id=f"c{b}.mp4", feats=x[b, :, :n].clone(), fps=25.0, duration=n / 25.0,
+                    feat_stride=1.0, feat_num_frames=1.0)
+        with torch.no_grad():
+            res = model([clip])[0]
+            o = R.infer_clip(sd, cfg, x[b, :, :n], dict(fps=25.0, duration=n / 25.0, feat_stride=1.0,
+                                                       feat_num_frames=1.0))
+        k = res["segments"].shape[0]
+        assert o["segments"].shape[0] == k, (o["segments"].shape, k)
+        ds, dsc, perm = match_segments(res["segments"], res["scores"], o["segments"], o["scores"])
+        print(f"[{name}] clip {b}: {k} segments, oracle-vs-ref seg diff {ds:.3e} score diff {dsc:.3e} "
+              f"(rank moves among near-ties: {int((perm != torch.arange(k)).sum())})")
+        assert ds < 2e-3 and dsc < 1e-4
+        kp = np.full((cfg["max_seg_num"],), -1, np.int64)
+        kp[:k] = o["kept_points"][perm].numpy()       # point index of each REFERENCE segment
+        kept_all.append(kp)
+        pad = np.zeros((cfg["max_seg_num"], 2), np.float32)
+        pad[:k] = res["segments"].numpy()
+        sp = np.zeros((cfg["max_seg_num"],), np.float32)
+        sp[:k] = res["scores"].numpy()
+        segs_all.append(pad)
+        scores_all.append(sp)
+        n_all.append(k)
+        vc_all.append(res["video_cls"].numpy())
+    out.update(segments=np.stack(segs_all), scores=np.stack(scores_all), n_segments=np.asarray(n_all),
+               video_cls=np.stack(vc_all), kept_points=np.stack(kept_all))
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+    return model, sd, x, mask
+
+
+def case_train(name, cfg, lens, wseed, xseed, ctx):
+    """Training-mode losses + a few gradients with drop-path / dropout disabled
+    (drop_prob=0 -> drop_path is the identity, blocks.py:1401-1402)."""
+    load_config, C, make_meta_arch = ctx
+    model, _ = ref_model(load_config, C, make_meta_arch, "deepfake_exp10.yaml", cfg)
+    sd = R.synth_state_dict(R.param_shapes(cfg), wseed, True)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for mod in model.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    model.interpolator.dp1.p = 0.0
+    x, mask = synth_inputs(cfg, lens, xseed)
+    rs = np.random.RandomState(xseed + 7)
+    vids, gts, gls = [], [], []
+    for b, n in enumerate(lens):
+        if b % 2 == 0:
+            k = 1 + b % 3
+            st = np.sort(rs.uniform(0, n - 20, size=k)).astype(np.float32)
+            ln = rs.uniform(2.0, 18.0, size=k).astype(np.float32)
+            seg = torch.from_numpy(np.stack([st, st + ln], 1))
+            lab = torch.zeros(k, dtype=torch.int64)
+        else:
+            seg, lab = None, None
+        gts.append(seg)
+        gls.append(lab)
+        vids.append(dict(video_id=f"c{b}", feats=x[b, :, :n].clone(), segments=seg, labels=lab, fps=25.0,
+                         duration=n / 25.0, feat_stride=1.0, feat_num_frames=1.0))
+    losses = model(vids)
+    losses["final_loss"].backward()
+    # oracle
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = R.model_forward(sdg, cfg, x, mask, training=True)
+    ol, norm, npos = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"])
+    ol["final_loss"].backward()
+    for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss"):
+        print(f"[{name}] {k}: ref {float(losses[k]):.6f} oracle {float(ol[k]):.6f}")
+        assert abs(float(losses[k]) - float(ol[k])) < 1e-4 * max(1.0, abs(float(losses[k])))
+    assert abs(norm - model.loss_normalizer) < 1e-6
+    gkeys = ["backbone.embd.0.conv.weight", "backbone.stem.0.attn.query.weight",
+             "backbone.branch.4.attn.value_conv.conv.weight", "backbone.lh_branch.2.mlp.3.weight",
+             "backbone.hh_branch.0.attn.key_norm.weight", "backbone.branch.1.drop_path_attn.scale",
+             "neck.fpn_convs.3.conv.weight", "cls_head.cls_head.conv.bias", "reg_head.scale.2.scale",
+             "reg_head.offset_head.conv.weight", "interpolator.contraction.down_3.conv_block.conv.weight",
+             "interpolator.conv1.weight", "interpolator.bn1.bias"]
+    named = dict(model.named_parameters())
+    store = {}
+    worst = 0.0
+    for k in gkeys:
+        g = named[k].grad
+        go = sdg[k].grad
+        rel = float((g - go).abs().max() / (g.abs().max() + 1e-12))
+        worst = max(worst, rel)
+        flat = g.flatten()
+        stride = max(1, flat.numel() // 4096)
+        store["grad::" + k] = flat[::stride][:4096].numpy().copy()   # strided sample (fixtures stay small)
+        store["gsum::" + k] = np.array([float(flat.double().sum()), float(flat.double().abs().sum())])
+    print(f"[{name}] worst relative grad diff oracle vs ref: {worst:.3e}")
+    assert worst < 2e-3
+    dead = sorted(k for k, p in named.items() if p.grad is None)
+    np.savez_compressed(
+        os.path.join(GOLD, f"{name}.npz"), lens=np.asarray(lens), wseed=wseed, xseed=xseed,
+        gt_segments=np.array([np.zeros((0, 2), np.float32) if g is None else g.numpy() for g in gts],
+                             dtype=object),
+        is_fake=np.array([g is not None for g in gts]),
+        losses=np.array([float(losses[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")]),
+        loss_normalizer=float(model.loss_normalizer), num_dead=len(dead),
+        dead_prefixes=np.array(sorted({".".join(d.split(".")[:3]) for d in dead})), **store)
+
+
+def case_nms():
+    import nms_1d_cpu
+    from libs.utils import batched_nms
+    rs = np.random.RandomState(5)
+    cases = {}
+    for i, n in enumerate([0, 1, 2, 7, 64, 300, 1512]):
+        st = rs.uniform(0, 700, n).astype(np.float32)
+        ln = rs.uniform(0.01, 40, n).astype(np.float32)
+        segs = np.stack([st, st + ln], 1).astype(np.float32).reshape(n, 2)
+        sc = rs.uniform(0.0, 1.0, n).astype(np.float32)
+        if n >= 64:                       # exact score ties and duplicate segments
+            sc[10:20] = sc[10]
+            segs[30:34] = segs[30]
+        keep = nms_1d_cpu.nms(torch.from_numpy(segs), torch.from_numpy(sc), 0.1).numpy() if n else np.zeros(0, np.int64)
+        cases[f"segs{i}"], cases[f"scores{i}"], cases[f"keep{i}"] = segs, sc, keep
+        for tag, ms in (("a", 0.001), ("b", 0.2)):
+            s, c, l = batched_nms(torch.from_numpy(segs), torch.from_numpy(sc), torch.zeros(n, dtype=torch.int64),
+                                  0.1, ms, 100, use_soft_nms=False, multiclass=False, sigma=0.75, voting_thresh=0.9)
+            cases[f"bn_segs{i}{tag}"], cases[f"bn_scores{i}{tag}"] = s.numpy(), c.numpy()
+    cases["n_cases"] = 7
+    np.savez_compressed(os.path.join(GOLD, "nms.npz"), **cases)
+    print("[nms] stored", cases["n_cases"], "cases")
+
+
+def case_interp():
+    import torch.nn.functional as F
+    out = {}
+    # known answer quoted in the reference source (deepfake_video_audio.py:1726)
+    ka = F.interpolate(torch.tensor([[[1.0, 2.0, 3.0, 4.0]]]), size=8, mode="linear", align_corners=False)
+    assert torch.allclose(ka[0, 0], torch.tensor([1.0, 1.25, 1.75, 2.25, 2.75, 3.25, 3.75, 4.0]))
+    out["known_in"] = np.array([1.0, 2.0, 3.0, 4.0], np.float32)
+    out["known_out"] = ka[0, 0].numpy()
+    rs = np.random.RandomState(11)
+    for i, (tv, ta, te) in enumerate([(216, 107, 431), (768, 383, 1535), (5, 1, 3), (900, 12, 2000)]):
+        v = rs.standard_normal((tv, 6)).astype(np.float32)
+        a = rs.standard_normal((ta, 10)).astype(np.float32)
+        e = rs.standard_normal((te, 4)).astype(np.float32)
+        feats = R.interp_concat([v, a, e], 768)
+        # the same with the reference's literal op sequence (deepfake_video_audio.py:1722-1756)
+        vv = torch.from_numpy(np.ascontiguousarray(v.transpose()))
+        if vv.shape[-1] != 768:
+            vv = F.interpolate(vv.unsqueeze(0), size=768, mode="linear", align_corners=False).squeeze(0)
+        aa = F.interpolate(torch.from_numpy(np.ascontiguousarray(a.transpose())).unsqueeze(0), size=768,
+                           mode="linear", align_corners=False).squeeze(0)
+        ee = F.interpolate(torch.from_numpy(np.ascontiguousarray(e.transpose())).unsqueeze(0), size=768,
+                           mode="linear", align_corners=False).squeeze(0)
+        ref = torch.cat([vv, aa, ee], 0)
+        assert torch.equal(ref, feats)
+        out[f"v{i}"], out[f"a{i}"], out[f"e{i}"], out[f"out{i}"] = v, a, e, ref.numpy()
+    out["n_cases"] = 4
+    np.savez_compressed(os.path.join(GOLD, "interp.npz"), **out)
+    print("[interp] stored 4 cases + known answer")
+
+
+SMALL = dict(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, head_dim=32)
+MID = dict(input_dim=192, max_seq_len=384, embd_dim=128, n_head=4, fpn_dim=128, head_dim=128)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    ctx = import_reference()
+    case_interp()
+    case_nms()
+    case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
+    case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
+    case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)
+    case_train("train_small", R.make_cfg(**SMALL), [192, 150, 180, 192], 3, 9, ctx)
+    case_train("train_mid", R.make_cfg(**MID), [384, 300, 350, 200], 7, 10, ctx)
+    case_forward("fwd_exp10", R.make_cfg(), [768, 700], 21, 22, ctx)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
