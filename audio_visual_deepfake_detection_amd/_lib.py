@@ -1,0 +1,90 @@
+"""ctypes binding of libavdf_hip.so (the C ABI declared in include/avdf.h).
+
+The library is built in-tree by `audio_visual_deepfake_detection_amd.csrc.build` (hipcc,
+--offload-arch=gfx950).  There is NO fallback: if the shared object is missing or a symbol
+cannot be resolved, importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavdf_hip.so")
+
+P, I, F, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> (restype, argtypes); must match include/avdf.h
+SIGNATURES = {
+    "avdf_last_error": (ctypes.c_char_p, []),
+    "avdf_version": (I, []),
+    "avdf_conv1d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "avdf_conv1d_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "avdf_conv1d_bwd_weight_ws": (L, [I, I, I, I, I]),
+    "avdf_conv1d_bwd_weight": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "avdf_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P, P, I, P]),
+    "avdf_layernorm_bwd_ws": (L, [I, I]),
+    "avdf_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "avdf_dwconv_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "avdf_dwconv_bwd_ws": (L, [I, I, I]),
+    "avdf_dwconv_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "avdf_local_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_local_attn_bwd_ws": (L, [I, I, I, I]),
+    "avdf_local_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_global_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_global_attn_bwd_ws": (L, [I, I, I, I]),
+    "avdf_global_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_maxpool3s2_fwd": (I, [P, P, I, I, I, P]),
+    "avdf_maxpool3s2_bwd": (I, [P, P, P, I, I, I, P]),
+    "avdf_affine_residual_fwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "avdf_affine_residual_bwd_ws": (L, [I, I, I]),
+    "avdf_affine_residual_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "avdf_upsample_fwd": (I, [P, P, I, I, I, I, P]),
+    "avdf_upsample_bwd": (I, [P, P, I, I, I, I, P]),
+    "avdf_downsample_fwd": (I, [P, P, I, I, I, I, P]),
+    "avdf_downsample_bwd": (I, [P, P, I, I, I, I, P]),
+    "avdf_add_upsampled": (I, [P, P, P, I, I, I, I, P]),
+    "avdf_scale_rows": (I, [P, P, P, I, I, P]),
+    "avdf_transpose": (I, [P, P, I, I, I, P]),
+    "avdf_instnorm_lrelu_fwd": (I, [P, P, P, P, I, I, I, F, F, P]),
+    "avdf_instnorm_lrelu_bwd": (I, [P, P, P, P, P, I, I, I, F, P]),
+    "avdf_maxavgpool_fwd": (I, [P, P, I, I, I, P]),
+    "avdf_maxavgpool_bwd": (I, [P, P, P, I, I, I, P]),
+    "avdf_smallconv_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "avdf_smallconv_bwd_ws": (L, [I, I, I, I, I]),
+    "avdf_smallconv_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "avdf_interp_linear": (I, [P, P, I, I, I, I, I, P]),
+    "avdf_loc_losses_ws": (L, [I, I]),
+    "avdf_loc_assign": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
+    "avdf_loc_losses": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, F, P]),
+    "avdf_decode_nms": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, F, F, I, P]),
+    "avdf_nms1d_host": (I, [P, P, L, F, P, P]),
+    "avdf_sumsq_ws": (L, []),
+    "avdf_sumsq": (I, [P, P, P, L, P]),
+    "avdf_adamw_ema": (I, [P, P, P, P, P, P, L, F, F, F, F, F, F, F, F, F, P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). Build it with "
+            "`python -m audio_visual_deepfake_detection_amd.csrc.build` or `__graft_entry__.build()`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class AvdfError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    """Mirror of the reference's error behaviour: Python exceptions (the C ABI returns int codes)."""
+    if rc != 0:
+        msg = lib.avdf_last_error()
+        raise AvdfError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,339 @@
+// Attention cores.
+//  * local (banded) attention -- LocalMaskedMHCA / LocalMaskedMMHCA steps 3-4
+//    (libs/modeling/blocks.py:739-778, 1181-1221).  With window 7 there are only 7 dot products
+//    of length hs per (query, head): this is an HBM/L2-bound gather, not an MFMA shape, so it is
+//    done with one wavefront per (b, t, head) and 64-lane shuffle reductions.
+//  * global attention of the last pyramid level -- MaskedMHCA core (blocks.py:299-309).
+// Layout: q,k,v,out [B,T,H*hs] time-major, head h = channels [h*hs, (h+1)*hs).
+#include "common.h"
+
+namespace {
+
+template <int W>
+__global__ __launch_bounds__(256) void local_attn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kvmask, float* __restrict__ out, float* __restrict__ probs,
+    int B, int T, int H, int hs, float scale) {
+  constexpr int w = W / 2;
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * T * H) return;
+  const int h = (int)(g % H);
+  const long bt = g / H;
+  const int t = (int)(bt % T);
+  const long b = bt / T;
+  const int C = H * hs;
+  const bool on = lane < hs;
+  const float qd = on ? q[bt * C + h * hs + lane] * scale : 0.f;
+  float s[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int tk = t + j - w;
+    if (tk >= 0 && tk < T) {
+      const float kd = on ? k[(b * T + tk) * C + h * hs + lane] : 0.f;
+      float d = wave_sum(qd * kd);
+      d += (kvmask[b * T + tk] == 0.f) ? -1e4f : 0.f;
+      s[j] = d;
+    } else {
+      s[j] = -INFINITY;
+    }
+  }
+  float m = s[0];
+#pragma unroll
+  for (int j = 1; j < W; ++j) m = fmaxf(m, s[j]);
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) { s[j] = __expf(s[j] - m); den += s[j]; }
+  const float rowm = kvmask[b * T + t];       // masked query rows are zeroed after the softmax
+  const float inv = rowm / den;
+  float o = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int tk = t + j - w;
+    const float p = s[j] * inv;
+    if (probs && lane == 0) probs[(bt * H + h) * W + j] = p;
+    if (tk >= 0 && tk < T && on) o += p * v[(b * T + tk) * C + h * hs + lane];
+  }
+  if (on) out[bt * C + h * hs + lane] = o;
+}
+
+// pass A: dS (to ws) and dq, one wave per (b,t,h)
+template <int W>
+__global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(
+    const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ probs, float* __restrict__ dq, float* __restrict__ dS,
+    int B, int T, int H, int hs, float scale) {
+  constexpr int w = W / 2;
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * T * H) return;
+  const int h = (int)(g % H);
+  const long bt = g / H;
+  const int t = (int)(bt % T);
+  const long b = bt / T;
+  const int C = H * hs;
+  const bool on = lane < hs;
+  const float go = on ? dout[bt * C + h * hs + lane] : 0.f;
+  float dp[W], p[W];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int tk = t + j - w;
+    p[j] = probs[(bt * H + h) * W + j];
+    if (tk >= 0 && tk < T) {
+      const float vd = on ? v[(b * T + tk) * C + h * hs + lane] : 0.f;
+      dp[j] = wave_sum(go * vd);
+    } else {
+      dp[j] = 0.f;
+    }
+    dot += p[j] * dp[j];
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int tk = t + j - w;
+    const float ds = p[j] * (dp[j] - dot);
+    if (lane == 0) dS[(bt * H + h) * W + j] = ds;
+    if (tk >= 0 && tk < T && on) acc += ds * k[(b * T + tk) * C + h * hs + lane];
+  }
+  if (on) dq[bt * C + h * hs + lane] = acc * scale;
+}
+
+// pass B: dk, dv gathered per key position, one wave per (b,s,h)
+template <int W>
+__global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(
+    const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ probs,
+    const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv,
+    int B, int T, int H, int hs, float scale) {
+  constexpr int w = W / 2;
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * T * H) return;
+  const int h = (int)(g % H);
+  const long bs = g / H;
+  const int s = (int)(bs % T);
+  const long b = bs / T;
+  const int C = H * hs;
+  if (lane >= hs) return;
+  float ak = 0.f, av = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int t = s - (j - w);            // query t sees key s in its band slot j
+    if (t >= 0 && t < T) {
+      const long bt = b * T + t;
+      const float ds = dS[(bt * H + h) * W + j];
+      const float p = probs[(bt * H + h) * W + j];
+      ak += ds * q[bt * C + h * hs + lane];
+      av += p * dout[bt * C + h * hs + lane];
+    }
+  }
+  dk[bs * C + h * hs + lane] = ak * scale;
+  dv[bs * C + h * hs + lane] = av;
+}
+
+constexpr int kGMaxSlots = 4;   // Tk <= 256
+
+// one wave per (b, h, tq); probs [B,H,Tq,Tk]
+__global__ __launch_bounds__(256) void global_attn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kvmask, float* __restrict__ out, float* __restrict__ probs,
+    int B, int Tq, int Tk, int H, int hs, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * H * Tq) return;
+  const int tq = (int)(g % Tq);
+  const int h = (int)((g / Tq) % H);
+  const long b = g / ((long)Tq * H);
+  const int C = H * hs;
+  const float qd = lane < hs ? q[(b * Tq + tq) * C + h * hs + lane] * scale : 0.f;
+  float s[kGMaxSlots];
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) s[u] = 0.f;
+  for (int d = 0; d < hs; ++d) {
+    const float qv = __shfl(qd, d, 64);
+#pragma unroll
+    for (int u = 0; u < kGMaxSlots; ++u) {
+      const int kk = u * 64 + lane;
+      if (kk < Tk) s[u] += qv * k[(b * Tk + kk) * C + h * hs + d];
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) {
+    const int kk = u * 64 + lane;
+    if (kk >= Tk || kvmask[b * Tk + kk] == 0.f) s[u] = -INFINITY;
+    m = fmaxf(m, s[u]);
+  }
+  m = wave_max(m);
+  float den = 0.f;
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) { s[u] = __expf(s[u] - m); den += s[u]; }   // exp(-inf)=0
+  den = wave_sum(den);
+  const float inv = 1.0f / den;
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) {
+    const int kk = u * 64 + lane;
+    s[u] *= inv;
+    if (probs && kk < Tk) probs[((b * H + h) * Tq + tq) * Tk + kk] = s[u];
+  }
+  float o = 0.f;
+  for (int kk = 0; kk < Tk; ++kk) {
+    const int u = kk >> 6;
+    const float src = u == 0 ? s[0] : (u == 1 ? s[1] : (u == 2 ? s[2] : s[3]));
+    const float p = __shfl(src, kk & 63, 64);
+    if (lane < hs) o += p * v[(b * Tk + kk) * C + h * hs + lane];    // p == 0 on masked keys (v*mask)
+  }
+  if (lane < hs) out[(b * Tq + tq) * C + h * hs + lane] = o;
+}
+
+// pass A: dS -> ws [B,H,Tq,Tk], dq
+__global__ __launch_bounds__(256) void global_attn_bwd_q_kernel(
+    const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ probs, float* __restrict__ dq, float* __restrict__ dS,
+    int B, int Tq, int Tk, int H, int hs, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * H * Tq) return;
+  const int tq = (int)(g % Tq);
+  const int h = (int)((g / Tq) % H);
+  const long b = g / ((long)Tq * H);
+  const int C = H * hs;
+  const float go = lane < hs ? dout[(b * Tq + tq) * C + h * hs + lane] : 0.f;
+  float dp[kGMaxSlots], p[kGMaxSlots];
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) dp[u] = 0.f;
+  for (int d = 0; d < hs; ++d) {
+    const float gv = __shfl(go, d, 64);
+#pragma unroll
+    for (int u = 0; u < kGMaxSlots; ++u) {
+      const int kk = u * 64 + lane;
+      if (kk < Tk) dp[u] += gv * v[(b * Tk + kk) * C + h * hs + d];
+    }
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) {
+    const int kk = u * 64 + lane;
+    p[u] = kk < Tk ? probs[((b * H + h) * Tq + tq) * Tk + kk] : 0.f;   // 0 on masked keys
+    dot += p[u] * dp[u];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int u = 0; u < kGMaxSlots; ++u) {
+    const int kk = u * 64 + lane;
+    dp[u] = p[u] * (dp[u] - dot);                                     // dS
+    if (kk < Tk) dS[((b * H + h) * Tq + tq) * Tk + kk] = dp[u];
+  }
+  float acc = 0.f;
+  for (int kk = 0; kk < Tk; ++kk) {
+    const int u = kk >> 6;
+    const float src = u == 0 ? dp[0] : (u == 1 ? dp[1] : (u == 2 ? dp[2] : dp[3]));
+    const float ds = __shfl(src, kk & 63, 64);
+    if (lane < hs) acc += ds * k[(b * Tk + kk) * C + h * hs + lane];
+  }
+  if (lane < hs) dq[(b * Tq + tq) * C + h * hs + lane] = acc * scale;
+}
+
+// pass B: one wave per (b,h,tk)
+__global__ __launch_bounds__(256) void global_attn_bwd_kv_kernel(
+    const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ probs,
+    const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv,
+    int B, int Tq, int Tk, int H, int hs, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * H * Tk) return;
+  const int tk = (int)(g % Tk);
+  const int h = (int)((g / Tk) % H);
+  const long b = g / ((long)Tk * H);
+  const int C = H * hs;
+  if (lane >= hs) return;
+  float ak = 0.f, av = 0.f;
+  for (int tq = 0; tq < Tq; ++tq) {
+    const long idx = ((b * H + h) * Tq + tq) * Tk + tk;
+    ak += dS[idx] * q[(b * Tq + tq) * C + h * hs + lane];
+    av += probs[idx] * dout[(b * Tq + tq) * C + h * hs + lane];
+  }
+  dk[(b * Tk + tk) * C + h * hs + lane] = ak * scale;
+  dv[(b * Tk + tk) * C + h * hs + lane] = av;     // masked keys have probs == 0 -> dv == 0
+}
+
+}  // namespace
+
+#define DISPATCH_W(W_, CALL)             \
+  switch (W_) {                          \
+    case 3: { CALL(3); break; }          \
+    case 5: { CALL(5); break; }          \
+    case 7: { CALL(7); break; }          \
+    case 9: { CALL(9); break; }          \
+    case 11: { CALL(11); break; }        \
+    case 13: { CALL(13); break; }        \
+    case 15: { CALL(15); break; }        \
+    case 17: { CALL(17); break; }        \
+    case 19: { CALL(19); break; }        \
+    default: avdf_set_error("local_attn: window %d unsupported (odd 3..19)", W_); return AVDF_EINVAL; \
+  }
+
+extern "C" int avdf_local_attn_fwd(const float* q, const float* k, const float* v, const float* kvmask,
+                                   float* out, float* probs, int B, int T, int H, int hs, int window,
+                                   float scale, void* stream) {
+  AVDF_REQUIRE(q && k && v && kvmask && out, "local_attn_fwd: null pointer");
+  AVDF_REQUIRE(B > 0 && T > 0 && H > 0 && hs > 0 && hs <= 64, "local_attn_fwd: bad dims (hs=%d must be <= 64)", hs);
+  hipStream_t st = (hipStream_t)stream;
+  const long waves = (long)B * T * H;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+#define CALL(WW) hipLaunchKernelGGL(local_attn_fwd_kernel<WW>, grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale)
+  DISPATCH_W(window, CALL)
+#undef CALL
+  AVDF_CHECK_LAUNCH("local_attn_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int64_t avdf_local_attn_bwd_ws(int B, int T, int H, int window) { return (int64_t)B * T * H * window; }
+
+extern "C" int avdf_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
+                                   const float* probs, float* dq, float* dk, float* dv, float* ws,
+                                   int B, int T, int H, int hs, int window, float scale, void* stream) {
+  AVDF_REQUIRE(dout && q && k && v && probs && dq && dk && dv && ws, "local_attn_bwd: null pointer");
+  AVDF_REQUIRE(B > 0 && T > 0 && H > 0 && hs > 0 && hs <= 64, "local_attn_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const long waves = (long)B * T * H;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+#define CALL(WW)                                                                                             \
+  hipLaunchKernelGGL(local_attn_bwd_q_kernel<WW>, grid, dim3(256), 0, st, dout, k, v, probs, dq, ws, B, T, H, hs, scale); \
+  hipLaunchKernelGGL(local_attn_bwd_kv_kernel<WW>, grid, dim3(256), 0, st, dout, q, probs, ws, dk, dv, B, T, H, hs, scale)
+  DISPATCH_W(window, CALL)
+#undef CALL
+  AVDF_CHECK_LAUNCH("local_attn_bwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_global_attn_fwd(const float* q, const float* k, const float* v, const float* kvmask,
+                                    float* out, float* probs, int B, int Tq, int Tk, int H, int hs,
+                                    float scale, void* stream) {
+  AVDF_REQUIRE(q && k && v && kvmask && out, "global_attn_fwd: null pointer");
+  AVDF_REQUIRE(B > 0 && Tq > 0 && Tk > 0 && Tk <= 64 * kGMaxSlots && H > 0 && hs > 0 && hs <= 64,
+               "global_attn_fwd: bad dims (Tk=%d <= %d, hs=%d <= 64)", Tk, 64 * kGMaxSlots, hs);
+  const long waves = (long)B * H * Tq;
+  hipLaunchKernelGGL(global_attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     q, k, v, kvmask, out, probs, B, Tq, Tk, H, hs, scale);
+  AVDF_CHECK_LAUNCH("global_attn_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int64_t avdf_global_attn_bwd_ws(int B, int Tq, int Tk, int H) { return (int64_t)B * H * Tq * Tk; }
+
+extern "C" int avdf_global_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
+                                    const float* kvmask, const float* probs, float* dq, float* dk, float* dv,
+                                    float* ws, int B, int Tq, int Tk, int H, int hs, float scale, void* stream) {
+  (void)kvmask;
+  AVDF_REQUIRE(dout && q && k && v && probs && dq && dk && dv && ws, "global_attn_bwd: null pointer");
+  AVDF_REQUIRE(B > 0 && Tq > 0 && Tk > 0 && Tk <= 64 * kGMaxSlots && H > 0 && hs > 0 && hs <= 64, "global_attn_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const long wq = (long)B * H * Tq, wk = (long)B * H * Tk;
+  hipLaunchKernelGGL(global_attn_bwd_q_kernel, dim3((unsigned)((wq + 3) / 4)), dim3(256), 0, st,
+                     dout, k, v, probs, dq, ws, B, Tq, Tk, H, hs, scale);
+  hipLaunchKernelGGL(global_attn_bwd_kv_kernel, dim3((unsigned)((wk + 3) / 4)), dim3(256), 0, st,
+                     dout, q, probs, ws, dk, dv, B, Tq, Tk, H, hs, scale);
+  AVDF_CHECK_LAUNCH("global_attn_bwd");
+  return AVDF_OK;
+}

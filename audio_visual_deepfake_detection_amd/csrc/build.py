@@ -1,0 +1,54 @@
+"""Builds libavdf_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m audio_visual_deepfake_detection_amd.csrc.build [--force] [--verbose]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "libavdf_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+SOURCES = ["gemm_conv.hip", "norm.hip", "attn.hip", "pointwise.hip", "smallconv.hip", "loss.hip",
+           "decode_nms.hip", "interp.hip", "optim.hip", "api.cpp"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=on"]
+
+
+def _stale(obj, deps):
+    return (not os.path.exists(obj)) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
+
+
+def build(force=False, verbose=False):
+    obj_dir = os.path.join(HERE, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "avdf.h")]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(obj_dir, s.rsplit(".", 1)[0] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(obj_dir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
+    if force or jobs or _stale(OUT, objs):
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

@@ -1,0 +1,63 @@
+// Shared helpers for the gfx950 kernels of libavdf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/avdf.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+void avdf_set_error(const char* fmt, ...);
+
+#define AVDF_REQUIRE(cond, ...)                    \
+  do {                                             \
+    if (!(cond)) {                                 \
+      avdf_set_error(__VA_ARGS__);                 \
+      return AVDF_EINVAL;                          \
+    }                                              \
+  } while (0)
+
+#define AVDF_CHECK_LAUNCH(name)                                         \
+  do {                                                                  \
+    hipError_t e_ = hipGetLastError();                                  \
+    if (e_ != hipSuccess) {                                             \
+      avdf_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return AVDF_ELAUNCH;                                              \
+    }                                                                   \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_f(float x, int act) {
+  if (act == AVDF_ACT_RELU) return fmaxf(x, 0.0f);
+  if (act == AVDF_ACT_GELU) return gelu_f(x);
+  return x;
+}
+__device__ __forceinline__ float act_grad_f(float pre, int act) {
+  if (act == AVDF_ACT_RELU) return pre > 0.0f ? 1.0f : 0.0f;
+  if (act == AVDF_ACT_GELU) return gelu_grad_f(pre);
+  return 1.0f;
+}
+
+// sum `nslab` partial vectors of length n: out[i] (+)= sum_s ws[s*n + i]
+int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int accumulate, hipStream_t st);

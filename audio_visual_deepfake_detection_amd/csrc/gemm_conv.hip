@@ -1,0 +1,606 @@
+// Dense conv1d (K in {1,3}, stride in {1,2}) as an implicit GEMM on the exact-fp32 matrix
+// cores of gfx950 (v_mfma_f32_32x32x2_f32).  Activations are time-major [B,T,C]; weights keep
+// the reference Conv1d layout [Cout, Cin, K] and are consumed as they lie (a K-tile of a weight
+// row is one contiguous run of KC*K floats), so no repacking happens at load_state_dict or
+// after an optimiser step.
+//
+//   forward : y[(b,t), n]   = sum_{k,c} x[b, t*S+k-P, c] * w[n,c,k]        (M = B*Tout, N = Cout)
+//   dgrad   : dx[(b,t'), c] = sum_{k,n} g[b, (t'+P-k)/S, n] * w[n,c,k]     (M = B*Tin,  N = Cin)
+//   wgrad   : dw[n, (c,k)]  = sum_{b,t} g[b,t,n] * x[b, t*S+k-P, c]        (M = Cout,   N = Cin x K)
+//
+// All three stage their operand tiles through LDS with a register prefetch of the next K-tile
+// (global loads in flight under the MFMA phase), 4 waves per workgroup, each wave owning
+// MI x NI accumulator tiles of 32x32.  MFMA operand maps (one f32 per lane):
+//   A[i = lane&31][k = lane>>5],  B[k = lane>>5][j = lane&31],
+//   D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//
+// Replaces: MaskedConv1D / nn.Conv1d(k=1) / nn.Linear of libs/modeling/blocks.py:41-63,
+// 957-966, 1291-1297, 1498-1505 and their autograd-generated backward.
+#include "common.h"
+
+namespace {
+
+template <int N>
+struct F4Buf { float4 v[N]; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// g = dy * mask[row] * act'(pre)
+__device__ __forceinline__ float4 grad_prologue(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                const float* __restrict__ ypre, size_t row, size_t off, int act) {
+  float4 g = ld4(dy + off);
+  if (ypre != nullptr && act != AVDF_ACT_NONE) {
+    const float4 p = ld4(ypre + off);
+    g.x *= act_grad_f(p.x, act); g.y *= act_grad_f(p.y, act);
+    g.z *= act_grad_f(p.z, act); g.w *= act_grad_f(p.w, act);
+  }
+  if (mask != nullptr) {
+    const float m = mask[row];
+    g.x *= m; g.y *= m; g.z *= m; g.w *= m;
+  }
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ ypre,
+    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
+  constexpr int RA = (BM - 1) * S + KS;
+  constexpr int LDA = KC + 1;
+  constexpr int KB = KC * KS;
+  constexpr int LDB = KB + 1;
+  constexpr int A4 = KC / 4, B4 = KB / 4;
+  constexpr int NA = (RA * A4 + 255) / 256, NB = (BN * B4 + 255) / 256;
+  __shared__ float As[RA * LDA];
+  __shared__ float Bs[BN * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / tilesT, t0 = (blockIdx.x % tilesT) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  F4Buf<NA> ra;
+  F4Buf<NB> rb;
+  auto load_tile = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + i * 256;
+      float4 v = zero4();
+      if (q < RA * A4) {
+        const int row = q / A4, c = c0 + (q % A4) * 4;
+        const int tr = t0 * S - P + row;
+        if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + tr) * Cin + c);
+      }
+      ra.v[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + i * 256;
+      float4 v = zero4();
+      if (q < BN * B4) {
+        const int n = n0 + q / B4, e = c0 * KS + (q % B4) * 4;
+        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * Cin * KS + e);
+      }
+      rb.v[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + i * 256;
+      if (q < RA * A4) {
+        float* d = As + (q / A4) * LDA + (q % A4) * 4;
+        d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + i * 256;
+      if (q < BN * B4) {
+        float* d = Bs + (q / B4) * LDB + (q % B4) * 4;
+        d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
+      }
+    }
+  };
+
+  const int nk = (Cin + KC - 1) / KC;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile((kt + 1) * KC);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+#pragma unroll
+      for (int cc = 0; cc < KC; cc += 2) {
+        float a[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          a[mi] = As[(((wm * MI + mi) * 32 + li) * S + k) * LDA + cc + lh];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          bv[ni] = Bs[((wn * NI + ni) * 32 + li) * LDB + (cc + lh) * KS + k];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + (wn * NI + ni) * 32 + li;
+      if (n >= Cout) continue;
+      const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (t >= Tout) continue;
+        const size_t row = (size_t)b * Tout + t;
+        float v = acc[mi][ni][r] + bn;
+        if (ypre) ypre[row * Cout + n] = v;
+        v = act_f(v, act);
+        if (mask) v *= mask[row];
+        y[row * Cout + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// data gradient
+// ------------------------------------------------------------------------------------------
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC>
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(
+    const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ mask,
+    const float* __restrict__ ypre, float* __restrict__ dx,
+    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
+  constexpr int RA = (BM + KS - 2) / S + 2;
+  constexpr int LDA = KC + 1;
+  constexpr int LDB = BN * KS;
+  constexpr int A4 = KC / 4, B4 = LDB / 4;
+  constexpr int NA = (RA * A4 + 255) / 256, NB = (KC * B4 + 255) / 256;
+  __shared__ float As[RA * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / tilesT, tp0 = (blockIdx.x % tilesT) * BM;
+  const int c0 = blockIdx.y * BN;
+  const int tA0 = floordiv(tp0 + P - (KS - 1), S);
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // per (mi, k): LDS row of the dy tile this lane's output row reads, or -1 (stride-2 parity miss)
+  int arow[MI][KS];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int num = tp0 + (wm * MI + mi) * 32 + li + P - k;
+      int r = -1;
+      if (S == 1) r = num - tA0;
+      else if (((num % S) + S) % S == 0) r = floordiv(num, S) - tA0;
+      arow[mi][k] = (r >= 0 && r < RA) ? r : -1;
+    }
+
+  F4Buf<NA> ra;
+  F4Buf<NB> rb;
+  auto load_tile = [&](int nk0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + i * 256;
+      float4 v = zero4();
+      if (q < RA * A4) {
+        const int t = tA0 + q / A4, n = nk0 + (q % A4) * 4;
+        if (t >= 0 && t < Tout && n < Cout) {
+          const size_t row = (size_t)b * Tout + t;
+          v = grad_prologue(dy, mask, ypre, row, row * Cout + n, act);
+        }
+      }
+      ra.v[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + i * 256;
+      float4 v = zero4();
+      if (q < KC * B4) {
+        const int n = nk0 + q / B4, e = c0 * KS + (q % B4) * 4;
+        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * Cin * KS + e);
+      }
+      rb.v[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + i * 256;
+      if (q < RA * A4) {
+        float* d = As + (q / A4) * LDA + (q % A4) * 4;
+        d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + i * 256;
+      if (q < KC * B4) *reinterpret_cast<float4*>(Bs + (q / B4) * LDB + (q % B4) * 4) = rb.v[i];
+    }
+  };
+
+  const int nk = (Cout + KC - 1) / KC;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile((kt + 1) * KC);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+#pragma unroll
+      for (int nn = 0; nn < KC; nn += 2) {
+        float a[MI], bv[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int r = arow[mi][k];
+          a[mi] = r >= 0 ? As[r * LDA + nn + lh] : 0.f;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          bv[ni] = Bs[(nn + lh) * LDB + ((wn * NI + ni) * 32 + li) * KS + k];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int c = c0 + (wn * NI + ni) * 32 + li;
+      if (c >= Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tp = tp0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (tp >= Tin) continue;
+        dx[((size_t)b * Tin + tp) * Cin + c] = acc[mi][ni][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient (split over the token dimension; partial tiles go to slabs)
+// ------------------------------------------------------------------------------------------
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mask,
+    const float* __restrict__ ypre, float* __restrict__ out,
+    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip, int tilesPerSplit,
+    int accumulate) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
+  constexpr int RX = (KT - 1) * S + KS;
+  constexpr int Y4 = BM / 4, X4 = BN / 4;
+  constexpr int NY = (KT * Y4 + 255) / 256, NX = (RX * X4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Ys[KT * BM];
+  __shared__ __attribute__((aligned(16))) float Xs[RX * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * BM, c0 = blockIdx.y * BN;
+  const int gbeg = blockIdx.z * tilesPerSplit;
+  int gend = gbeg + tilesPerSplit;
+  const int gtot = B * tilesPerClip;
+  if (gend > gtot) gend = gtot;
+
+  floatx16 acc[MI][NI][KS];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][k][r] = 0.f;
+
+  F4Buf<NY> ry;
+  F4Buf<NX> rx;
+  auto load_tile = [&](int g) {
+    const int b = g / tilesPerClip, tt0 = (g % tilesPerClip) * KT;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int q = tid + i * 256;
+      float4 v = zero4();
+      if (q < KT * Y4) {
+        const int t = tt0 + q / Y4, n = n0 + (q % Y4) * 4;
+        if (t < Tout && n < Cout) {
+          const size_t row = (size_t)b * Tout + t;
+          v = grad_prologue(dy, mask, ypre, row, row * Cout + n, act);
+        }
+      }
+      ry.v[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = tid + i * 256;
+      float4 v = zero4();
+      if (q < RX * X4) {
+        const int tr = tt0 * S - P + q / X4, c = c0 + (q % X4) * 4;
+        if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + tr) * Cin + c);
+      }
+      rx.v[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int q = tid + i * 256;
+      if (q < KT * Y4) *reinterpret_cast<float4*>(Ys + (q / Y4) * BM + (q % Y4) * 4) = ry.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = tid + i * 256;
+      if (q < RX * X4) *reinterpret_cast<float4*>(Xs + (q / X4) * BN + (q % X4) * 4) = rx.v[i];
+    }
+  };
+
+  if (gbeg < gend) {
+    load_tile(gbeg);
+    store_tile();
+  }
+  __syncthreads();
+  for (int g = gbeg; g < gend; ++g) {
+    if (g + 1 < gend) load_tile(g + 1);
+#pragma unroll
+    for (int tl = 0; tl < KT; tl += 2) {
+      float a[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = Ys[(tl + lh) * BM + (wm * MI + mi) * 32 + li];
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const float bv = Xs[((tl + lh) * S + k) * BN + (wn * NI + ni) * 32 + li];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][ni][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv, acc[mi][ni][k], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (g + 1 < gend) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  float* o = out + (gridDim.z > 1 ? (size_t)blockIdx.z * Cout * Cin * KS : 0);
+  const bool add = accumulate && gridDim.z == 1;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int c = c0 + (wn * NI + ni) * 32 + li;
+      if (c >= Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n >= Cout) continue;
+        float* d = o + ((size_t)n * Cin + c) * KS;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          if (add) d[k] += acc[mi][ni][k][r];
+          else d[k] = acc[mi][ni][k][r];
+        }
+      }
+    }
+}
+
+// column sums of g = dy*mask*act'(pre): partial[blockIdx.x][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                     const float* __restrict__ ypre, float* __restrict__ partial,
+                                                     int M, int N, int act) {
+  __shared__ float red[4][256];
+  const int tid = threadIdx.x, cg = tid & 63, rg = tid >> 6;
+  for (int nb = 0; nb < N; nb += 256) {
+    const int n = nb + cg * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+      for (int r = blockIdx.x * 4 + rg; r < M; r += gridDim.x * 4) {
+        const float4 g = grad_prologue(dy, mask, ypre, (size_t)r, (size_t)r * N + n, act);
+        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+      }
+    }
+    red[rg][cg * 4 + 0] = s.x; red[rg][cg * 4 + 1] = s.y; red[rg][cg * 4 + 2] = s.z; red[rg][cg * 4 + 3] = s.w;
+    __syncthreads();
+    if (nb + tid < N) partial[(size_t)blockIdx.x * N + nb + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                           int nslab, int64_t n, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += ws[(size_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+constexpr int kColsumBlocks = 128;
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles; bool small; };
+inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
+  WgradPlan p;
+  const int KT = 32;
+  p.small = ((int64_t)Cout * Cin * K <= 512 * 1024);
+  const int bm = p.small ? 64 : 128;
+  p.mtiles = cdiv(Cout, bm);
+  p.ctiles = cdiv(Cin, 64);
+  p.tilesPerClip = cdiv(Tout, KT);
+  const int total = B * p.tilesPerClip;
+  int want = cdiv(512, p.mtiles * p.ctiles);
+  if (want < 1) want = 1;
+  if (want > total) want = total;
+  p.tilesPerSplit = cdiv(total, want);
+  p.splits = cdiv(total, p.tilesPerSplit);
+  return p;
+}
+
+}  // namespace
+
+int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int accumulate, hipStream_t st) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, out, nslab, n, accumulate);
+  AVDF_CHECK_LAUNCH("reduce_slabs");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const float* mask,
+                               float* y, float* ypre, int B, int Tin, int Cin, int Tout, int Cout,
+                               int K, int stride, int act, void* stream) {
+  AVDF_REQUIRE(x && w && y, "conv1d_fwd: null pointer");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_fwd: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2), "conv1d_fwd: K in {1,3}, stride in {1,2}");
+  AVDF_REQUIRE(!(K == 1 && stride != 1), "conv1d_fwd: K=1 needs stride 1");
+  AVDF_REQUIRE(Cin % 4 == 0, "conv1d_fwd: Cin %% 4 != 0 (Cin=%d)", Cin);
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd: Tout=%d inconsistent with Tin=%d K=%d s=%d", Tout, Tin, K, stride);
+  AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd: x/w must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_FWD(KS_, S_, WM_, WN_, MI_, NI_)                                                     \
+  do {                                                                                              \
+    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                       \
+    const int tilesT = cdiv(Tout, BM_);                                                             \
+    dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                         \
+    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, 16>), grid, dim3(256), 0, st,  \
+                       x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT);            \
+  } while (0)
+  const bool big = (int64_t)B * Tout >= 4096;      // enough rows to fill the chip with 128-row tiles
+  if (K == 3 && stride == 1) { if (big) LAUNCH_FWD(3, 1, 2, 2, 2, 2); else LAUNCH_FWD(3, 1, 2, 2, 1, 2); }
+  else if (K == 3 && stride == 2) { if (big) LAUNCH_FWD(3, 2, 2, 2, 2, 2); else LAUNCH_FWD(3, 2, 2, 2, 1, 2); }
+  else { if (big) LAUNCH_FWD(1, 1, 2, 2, 2, 2); else LAUNCH_FWD(1, 1, 2, 2, 1, 2); }
+#undef LAUNCH_FWD
+  AVDF_CHECK_LAUNCH("conv1d_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,
+                                    float* dx, int B, int Tin, int Cin, int Tout, int Cout,
+                                    int K, int stride, int act, void* stream) {
+  AVDF_REQUIRE(dy && w && dx, "conv1d_bwd_data: null pointer");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_bwd_data: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_bwd_data: unsupported K/stride");
+  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_data: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_data: Tout inconsistent");
+  AVDF_REQUIRE(aligned16(dy) && aligned16(w) && (!ypre || aligned16(ypre)), "conv1d_bwd_data: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_DG(KS_, S_, WM_, WN_, MI_, NI_)                                                       \
+  do {                                                                                               \
+    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                        \
+    const int tilesT = cdiv(Tin, BM_);                                                               \
+    dim3 grid(B * tilesT, cdiv(Cin, BN_));                                                           \
+    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, 16>), grid, dim3(256), 0, st, \
+                       dy, w, mask, ypre, dx, B, Tin, Cin, Tout, Cout, act, tilesT);                 \
+  } while (0)
+  const bool big = (int64_t)B * Tin >= 4096;
+  if (K == 3 && stride == 1) { if (big) LAUNCH_DG(3, 1, 2, 2, 2, 2); else LAUNCH_DG(3, 1, 2, 2, 1, 2); }
+  else if (K == 3 && stride == 2) { if (big) LAUNCH_DG(3, 2, 2, 2, 2, 2); else LAUNCH_DG(3, 2, 2, 2, 1, 2); }
+  else { if (big) LAUNCH_DG(1, 1, 2, 2, 2, 2); else LAUNCH_DG(1, 1, 2, 2, 1, 2); }
+#undef LAUNCH_DG
+  AVDF_CHECK_LAUNCH("conv1d_bwd_data");
+  return AVDF_OK;
+}
+
+extern "C" int64_t avdf_conv1d_bwd_weight_ws(int B, int Tout, int Cin, int Cout, int K) {
+  const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
+  const int64_t slab = (p.splits > 1) ? (int64_t)p.splits * Cout * Cin * K : 0;
+  return slab + (int64_t)kColsumBlocks * Cout;
+}
+
+extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const float* mask, const float* ypre,
+                                      float* dw, float* dbias, float* ws, int B, int Tin, int Cin, int Tout,
+                                      int Cout, int K, int stride, int act, int accumulate, void* stream) {
+  AVDF_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight: null pointer");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_bwd_weight: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_bwd_weight: unsupported K/stride");
+  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_weight: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_weight: Tout inconsistent");
+  AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws) && (!ypre || aligned16(ypre)), "conv1d_bwd_weight: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
+  float* target = p.splits > 1 ? ws : dw;
+#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_)                                                        \
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, 32>),                            \
+                     dim3(p.mtiles, p.ctiles, p.splits), dim3(256), 0, st, dy, x, mask, ypre, target, \
+                     B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate)
+  if (p.small) {
+    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 1, 1);
+    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 1, 1);
+    else LAUNCH_WG(1, 1, 2, 2, 1, 1);
+  } else {
+    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 2, 1);
+    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 2, 1);
+    else LAUNCH_WG(1, 1, 2, 2, 2, 1);
+  }
+#undef LAUNCH_WG
+  AVDF_CHECK_LAUNCH("conv1d_bwd_weight");
+  if (p.splits > 1) {
+    int rc = avdf_reduce_slabs(ws, dw, p.splits, (int64_t)Cout * Cin * K, accumulate, st);
+    if (rc) return rc;
+  }
+  if (dbias) {
+    float* part = ws + (p.splits > 1 ? (size_t)p.splits * Cout * Cin * K : 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(kColsumBlocks), dim3(256), 0, st, dy, mask, ypre, part, B * Tout, Cout, act);
+    AVDF_CHECK_LAUNCH("colsum");
+    int rc = avdf_reduce_slabs(part, dbias, kColsumBlocks, Cout, accumulate, st);
+    if (rc) return rc;
+  }
+  return AVDF_OK;
+}

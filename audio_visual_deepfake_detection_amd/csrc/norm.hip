@@ -1,0 +1,305 @@
+// Normalisation kernels (HBM-bound, wave-shuffle reductions).
+//   * channel LayerNorm over the contiguous C axis of a time-major token row
+//     (libs/modeling/blocks.py:97-112), optional fused ReLU and "+pe*mask";
+//   * InstanceNorm1d (stats over T, incl. padded positions) + LeakyReLU of DownBlock
+//     (libs/modeling/blocks.py:1508-1516);
+//   * max+avg pooling over T (libs/modeling/blocks.py:1610-1614).
+#include "common.h"
+
+namespace {
+
+constexpr int kLnMaxV = 8;            // float4 per lane -> C <= 2048
+constexpr int kLnBwdBlocks = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+    int M, int C, float eps, int relu, const float* __restrict__ pe, const float* __restrict__ mask, int T) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wid;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * C;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) { v[j] = ld4(xr + c); s += v[j].x + v[j].y + v[j].z + v[j].w; }
+    else v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) {
+      const float a = v[j].x - mean, b = v[j].y - mean, d = v[j].z - mean, e = v[j].w - mean;
+      q += a * a + b * b + d * d + e * e;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  const float mk = (pe && mask) ? mask[row] : 1.0f;
+  const int t = pe ? row % T : 0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) {
+      float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gamma) { g = ld4(gamma + c); bb = ld4(beta + c); }
+      float4 o;
+      o.x = (v[j].x - mean) * rstd * g.x + bb.x;
+      o.y = (v[j].y - mean) * rstd * g.y + bb.y;
+      o.z = (v[j].z - mean) * rstd * g.z + bb.z;
+      o.w = (v[j].w - mean) * rstd * g.w + bb.w;
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (pe) {
+        const float4 p = ld4(pe + (size_t)t * C + c);
+        o.x += p.x * mk; o.y += p.y * mk; o.z += p.z * mk; o.w += p.w * mk;
+      }
+      *reinterpret_cast<float4*>(y + (size_t)row * C + c) = o;
+    }
+  }
+}
+
+// ws layout: [2][gridDim.x][C]  (dgamma partials, then dbeta partials)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+    float* __restrict__ dx, float* __restrict__ ws, int M, int C, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2][C]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float4 ag[NV], ab[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j]; }
+  for (int row = blockIdx.x * 4 + wid; row < M; row += gridDim.x * 4) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float4 xh[NV], gy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < C) {
+        const float4 xv = ld4(x + (size_t)row * C + c);
+        float4 d = ld4(dy + (size_t)row * C + c);
+        float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gamma) { g = ld4(gamma + c); bb = ld4(beta + c); }
+        float4 h;
+        h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
+        if (relu) {
+          if (h.x * g.x + bb.x <= 0.f) d.x = 0.f;
+          if (h.y * g.y + bb.y <= 0.f) d.y = 0.f;
+          if (h.z * g.z + bb.z <= 0.f) d.z = 0.f;
+          if (h.w * g.w + bb.w <= 0.f) d.w = 0.f;
+        }
+        ag[j].x += d.x * h.x; ag[j].y += d.y * h.y; ag[j].z += d.z * h.z; ag[j].w += d.w * h.w;
+        ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+        d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;
+        s1 += d.x + d.y + d.z + d.w;
+        s2 += d.x * h.x + d.y * h.y + d.z * h.z + d.w * h.w;
+        xh[j] = h; gy[j] = d;
+      } else { xh[j] = make_float4(0.f, 0.f, 0.f, 0.f); gy[j] = xh[j]; }
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < C) {
+        float4 o;
+        o.x = rstd * (gy[j].x - m1 - xh[j].x * m2);
+        o.y = rstd * (gy[j].y - m1 - xh[j].y * m2);
+        o.z = rstd * (gy[j].z - m1 - xh[j].z * m2);
+        o.w = rstd * (gy[j].w - m1 - xh[j].w * m2);
+        *reinterpret_cast<float4*>(dx + (size_t)row * C + c) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) {
+      *reinterpret_cast<float4*>(red + (size_t)(wid * 2 + 0) * C + c) = ag[j];
+      *reinterpret_cast<float4*>(red + (size_t)(wid * 2 + 1) * C + c) = ab[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    float s = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < 4; ++w_) s += red[(size_t)(w_ * 2 + which) * C + c];
+    ws[((size_t)which * gridDim.x + blockIdx.x) * C + c] = s;
+  }
+}
+
+// one workgroup per (b, 64-channel group); 256 threads = 64 channels x 4 time slices
+__global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+    int T, int C, float eps, float slope) {
+  __shared__ float red[4][64];
+  __shared__ float stat[2][64];
+  const int cl = threadIdx.x & 63, ts = threadIdx.x >> 6;
+  const int groups = (C + 63) / 64;
+  const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * 64 + cl;
+  const bool ok = c < C;
+  const float* xb = x + (size_t)b * T * C + c;
+  float s = 0.f;
+  if (ok) for (int t = ts; t < T; t += 4) s += xb[(size_t)t * C];
+  red[ts][cl] = s;
+  __syncthreads();
+  if (ts == 0) stat[0][cl] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)T;
+  __syncthreads();
+  const float mean = stat[0][cl];
+  float q = 0.f;
+  if (ok) for (int t = ts; t < T; t += 4) { const float d = xb[(size_t)t * C] - mean; q += d * d; }
+  red[ts][cl] = q;
+  __syncthreads();
+  if (ts == 0) {
+    const float var = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)T;
+    stat[1][cl] = 1.0f / sqrtf(var + eps);
+    if (ok && mean_o) { mean_o[(size_t)b * C + c] = mean; rstd_o[(size_t)b * C + c] = stat[1][cl]; }
+  }
+  __syncthreads();
+  const float rstd = stat[1][cl];
+  float* yb = y + (size_t)b * T * C + c;
+  if (ok) for (int t = ts; t < T; t += 4) {
+    const float h = (xb[(size_t)t * C] - mean) * rstd;
+    yb[(size_t)t * C] = h > 0.f ? h : h * slope;
+  }
+}
+
+__global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_i,
+    const float* __restrict__ rstd_i, float* __restrict__ dx, int T, int C, float slope) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, ts = threadIdx.x >> 6;
+  const int groups = (C + 63) / 64;
+  const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * 64 + cl;
+  const bool ok = c < C;
+  const size_t base = (size_t)b * T * C + c;
+  const float mean = ok ? mean_i[(size_t)b * C + c] : 0.f, rstd = ok ? rstd_i[(size_t)b * C + c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok) for (int t = ts; t < T; t += 4) {
+    const float h = (x[base + (size_t)t * C] - mean) * rstd;
+    const float g = dy[base + (size_t)t * C] * (h > 0.f ? 1.f : slope);
+    s1 += g; s2 += g * h;
+  }
+  red[0][ts][cl] = s1; red[1][ts][cl] = s2;
+  __syncthreads();
+  const float m1 = (red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]) / (float)T;
+  const float m2 = (red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]) / (float)T;
+  if (ok) for (int t = ts; t < T; t += 4) {
+    const float h = (x[base + (size_t)t * C] - mean) * rstd;
+    const float g = dy[base + (size_t)t * C] * (h > 0.f ? 1.f : slope);
+    dx[base + (size_t)t * C] = rstd * (g - m1 - h * m2);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxavgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int C) {
+  __shared__ float rmax[4][64], rsum[4][64];
+  const int cl = threadIdx.x & 63, ts = threadIdx.x >> 6;
+  const int groups = (C + 63) / 64;
+  const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * 64 + cl;
+  const bool ok = c < C;
+  float mx = -INFINITY, s = 0.f;
+  if (ok) for (int t = ts; t < T; t += 4) { const float v = x[((size_t)b * T + t) * C + c]; mx = fmaxf(mx, v); s += v; }
+  rmax[ts][cl] = mx; rsum[ts][cl] = s;
+  __syncthreads();
+  if (ts == 0 && ok) {
+    y[(size_t)b * 2 * C + c] = fmaxf(fmaxf(rmax[0][cl], rmax[1][cl]), fmaxf(rmax[2][cl], rmax[3][cl]));
+    y[(size_t)b * 2 * C + C + c] = (rsum[0][cl] + rsum[1][cl] + rsum[2][cl] + rsum[3][cl]) / (float)T;
+  }
+}
+
+// dx[b,t,c] = dy[b,c]*[t == first argmax] + dy[b,C+c]/T
+__global__ __launch_bounds__(256) void maxavgpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ dx, int T, int C) {
+  const int groups = (C + 255) / 256;
+  const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * 256 + threadIdx.x;
+  if (c >= C) return;
+  float mx = -INFINITY; int am = 0;
+  for (int t = 0; t < T; ++t) { const float v = x[((size_t)b * T + t) * C + c]; if (v > mx) { mx = v; am = t; } }
+  const float gm = dy[(size_t)b * 2 * C + c], ga = dy[(size_t)b * 2 * C + C + c] / (float)T;
+  for (int t = 0; t < T; ++t) dx[((size_t)b * T + t) * C + c] = ga + (t == am ? gm : 0.f);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int avdf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                  float* mean, float* rstd, int M, int C, float eps, int relu,
+                                  const float* pe, const float* mask, int T, void* stream) {
+  AVDF_REQUIRE(x && y && M > 0 && C > 0, "layernorm_fwd: bad args");
+  AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "layernorm_fwd: C must be a multiple of 4 and <= %d (C=%d)", 256 * kLnMaxV, C);
+  AVDF_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta must both be given or both NULL");
+  AVDF_REQUIRE((mean == nullptr) == (rstd == nullptr), "layernorm_fwd: mean/rstd must both be given or both NULL");
+  AVDF_REQUIRE(!pe || T > 0, "layernorm_fwd: pe needs T");
+  AVDF_REQUIRE(aligned16(x) && aligned16(y) && (!gamma || (aligned16(gamma) && aligned16(beta))) && (!pe || aligned16(pe)), "layernorm_fwd: 16-byte alignment");
+#define LN_FWD(NV_) hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, \
+                                      x, gamma, beta, y, mean, rstd, M, C, eps, relu, pe, mask, T)
+  if (C <= 256) LN_FWD(1); else if (C <= 512) LN_FWD(2); else if (C <= 1024) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
+  AVDF_CHECK_LAUNCH("layernorm_fwd");
+  return AVDF_OK;
+}
+
+static int ln_bwd_blocks(int M) { int g = cdiv(M, 4); return g < kLnBwdBlocks ? g : kLnBwdBlocks; }
+
+extern "C" int64_t avdf_layernorm_bwd_ws(int M, int C) { return (int64_t)2 * ln_bwd_blocks(M) * C; }
+
+extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                                  float* ws, int M, int C, int relu, int accumulate, void* stream) {
+  AVDF_REQUIRE(dy && x && mean && rstd && dx && ws && M > 0 && C > 0, "layernorm_bwd: bad args");
+  AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "layernorm_bwd: C must be a multiple of 4 and <= %d", 256 * kLnMaxV);
+  AVDF_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm_bwd: gamma/beta");
+  AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && (!gamma || (aligned16(gamma) && aligned16(beta))), "layernorm_bwd: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int G = ln_bwd_blocks(M);
+#define LN_BWD(NV_) hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(G), dim3(256), (size_t)8 * C * sizeof(float), st, \
+                                      dy, x, gamma, beta, mean, rstd, dx, ws, M, C, relu)
+  if (C <= 256) LN_BWD(1); else if (C <= 512) LN_BWD(2); else if (C <= 1024) LN_BWD(4); else LN_BWD(8);
+#undef LN_BWD
+  AVDF_CHECK_LAUNCH("layernorm_bwd");
+  if (dgamma) { int rc = avdf_reduce_slabs(ws, dgamma, G, C, accumulate, st); if (rc) return rc; }
+  if (dbeta) { int rc = avdf_reduce_slabs(ws + (size_t)G * C, dbeta, G, C, accumulate, st); if (rc) return rc; }
+  return AVDF_OK;
+}
+
+extern "C" int avdf_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
+                                       int B, int T, int C, float eps, float slope, void* stream) {
+  AVDF_REQUIRE(x && y && B > 0 && T > 0 && C > 0, "instnorm_lrelu_fwd: bad args");
+  AVDF_REQUIRE((mean == nullptr) == (rstd == nullptr), "instnorm_lrelu_fwd: mean/rstd");
+  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(B * cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, mean, rstd, T, C, eps, slope);
+  AVDF_CHECK_LAUNCH("instnorm_lrelu_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_instnorm_lrelu_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                       float* dx, int B, int T, int C, float slope, void* stream) {
+  AVDF_REQUIRE(dy && x && mean && rstd && dx && B > 0 && T > 0 && C > 0, "instnorm_lrelu_bwd: bad args");
+  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(B * cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream,
+                     dy, x, mean, rstd, dx, T, C, slope);
+  AVDF_CHECK_LAUNCH("instnorm_lrelu_bwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_maxavgpool_fwd(const float* x, float* y, int B, int T, int C, void* stream) {
+  AVDF_REQUIRE(x && y && B > 0 && T > 0 && C > 0, "maxavgpool_fwd: bad args");
+  hipLaunchKernelGGL(maxavgpool_fwd_kernel, dim3(B * cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, y, T, C);
+  AVDF_CHECK_LAUNCH("maxavgpool_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_maxavgpool_bwd(const float* dy, const float* x, float* dx, int B, int T, int C, void* stream) {
+  AVDF_REQUIRE(dy && x && dx && B > 0 && T > 0 && C > 0, "maxavgpool_bwd: bad args");
+  hipLaunchKernelGGL(maxavgpool_bwd_kernel, dim3(B * cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, T, C);
+  AVDF_CHECK_LAUNCH("maxavgpool_bwd");
+  return AVDF_OK;
+}

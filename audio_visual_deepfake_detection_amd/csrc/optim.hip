@@ -1,0 +1,85 @@
+// Optimiser step on flat fp32 buffers ("next" row of the scope table):
+//   grad-norm clipping (train_utils.py:306-310), AdamW (train_utils.py:125-144, torch.optim.AdamW
+//   semantics: decoupled weight decay), ModelEma update (train_utils.py:258-263) in ONE pass.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t n) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += red[0];
+}
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
+                                                        const float* __restrict__ gnorm_sq, int64_t n, float lr, float beta1,
+                                                        float beta2, float eps, float wd, float bias_c1, float bias_c2,
+                                                        float clip_norm, float ema_decay) {
+  float cs = 1.f;
+  if (gnorm_sq && clip_norm > 0.f) {
+    const float nrm = sqrtf(gnorm_sq[0]);
+    cs = fminf(clip_norm / (nrm + 1e-6f), 1.f);      // torch.nn.utils.clip_grad_norm_
+  }
+  const float step = lr / bias_c1;
+  const float inv_sqrt_c2 = 1.f / sqrtf(bias_c2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * cs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) * inv_sqrt_c2 + eps);
+    p[i] = pi;
+    if (ema) ema[i] = ema[i] * ema_decay + (1.f - ema_decay) * pi;
+  }
+}
+
+constexpr int kSumsqBlocks = 1024;
+
+}  // namespace
+
+extern "C" int64_t avdf_sumsq_ws(void) { return kSumsqBlocks; }
+
+extern "C" int avdf_sumsq(const float* x, float* out, float* ws, int64_t n, void* stream) {
+  AVDF_REQUIRE(x && out && ws && n > 0, "sumsq: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t nb = (n + 255) / 256;
+  if (nb > kSumsqBlocks) nb = kSumsqBlocks;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ws, n);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, out);
+  AVDF_CHECK_LAUNCH("sumsq");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
+                              int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                              float bias_c1, float bias_c2, float clip_norm, float ema_decay, void* stream) {
+  AVDF_REQUIRE(p && g && m && v && n > 0, "adamw_ema: bad args");
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, gnorm_sq, n,
+                     lr, beta1, beta2, eps, wd, bias_c1, bias_c2, clip_norm, ema_decay);
+  AVDF_CHECK_LAUNCH("adamw_ema");
+  return AVDF_OK;
+}

@@ -1,0 +1,392 @@
+"""Building blocks of the UMMAFormer path on MI355X.
+
+Same class names, constructor arguments and state-dict keys as the reference's
+libs/modeling/blocks.py, but every forward runs hand-written gfx950 kernels (through ..ops) on
+TIME-MAJOR activations:
+
+    x    : fp32 [B, T, C]   (reference: [B, C, T])
+    mask : fp32 [B, T]      (reference: bool [B, 1, T])
+
+Parameters keep the reference layouts (nn.Conv1d / nn.Linear / [1,C,1] holders), so reference
+checkpoints load unchanged and `make_optimizer`'s isinstance rules (train_utils.py:73-111) still
+classify every parameter.  The nn.Conv1d / nn.Linear members are parameter holders only; their
+aten forward is never called.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+
+
+def downsample_mask(mask, stride):
+    """Nearest-neighbour mask downsampling of MaskedConv1D (blocks.py:51-55) == mask[:, ::stride]."""
+    return mask if stride == 1 else mask[:, ::stride].contiguous()
+
+
+class MaskedConv1D(nn.Module):
+    """Masked 1-D convolution (blocks.py:13-63).  groups must be 1 (dense, MFMA implicit GEMM) or
+    in_channels (depthwise k3)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, padding_mode='zeros'):
+        super().__init__()
+        assert (kernel_size % 2 == 1) and (kernel_size // 2 == padding)
+        assert dilation == 1 and padding_mode == 'zeros'
+        assert groups == 1 or (groups == in_channels == out_channels and kernel_size == 3)
+        self.stride = stride
+        self.depthwise = groups > 1
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                              padding_mode)
+        if bias:
+            torch.nn.init.constant_(self.conv.bias, 0.)
+
+    def forward(self, x, mask, act=ops.ACT_NONE):
+        B, T, C = x.shape
+        assert T % self.stride == 0            # blocks.py:46
+        out_mask = downsample_mask(mask, self.stride)
+        if self.depthwise:
+            assert self.conv.bias is None
+            y = ops.dwconv(x, self.conv.weight, out_mask, self.stride)
+        else:
+            y = ops.conv1d(x, self.conv.weight, self.conv.bias, out_mask, self.stride, act)
+        return y, out_mask
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm over channels (blocks.py:70-112); weight/bias are [1, C, 1] like the reference."""
+
+    def __init__(self, num_channels, eps=1e-5, affine=True, device=None, dtype=None):
+        super().__init__()
+        kw = {'device': device, 'dtype': dtype}
+        self.num_channels, self.eps, self.affine = num_channels, eps, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones([1, num_channels, 1], **kw))
+            self.bias = nn.Parameter(torch.zeros([1, num_channels, 1], **kw))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+
+    def forward(self, x, relu=False, pe=None, mask=None):
+        assert x.shape[-1] == self.num_channels
+        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, pe, mask)
+
+
+def get_sinusoid_encoding(n_position, d_hid):
+    """Sinusoid table [1, C, T] (blocks.py:116-127), float64 maths cast to fp32."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    hid = np.arange(d_hid)[None, :]
+    table = pos / np.power(10000, 2 * (hid // 2) / d_hid)
+    table[:, 0::2] = np.sin(table[:, 0::2])
+    table[:, 1::2] = np.cos(table[:, 1::2])
+    return torch.FloatTensor(table).unsqueeze(0).transpose(1, 2)
+
+
+class Scale(nn.Module):
+    """Learnable scalar (blocks.py:1374-1392); applied inside the fused regression-head kernel."""
+
+    def __init__(self, init_value=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(init_value, dtype=torch.float32), requires_grad=True)
+
+
+class AffineDropPath(nn.Module):
+    """Per-channel scale + per-sample stochastic depth (blocks.py:1424-1439).  The scale and the
+    keep factor are consumed by the fused residual kernel; this module only owns the parameter
+    and draws the per-sample keep factors."""
+
+    def __init__(self, num_dim, drop_prob=0.0, init_scale_value=1e-4):
+        super().__init__()
+        self.scale = nn.Parameter(init_scale_value * torch.ones((1, num_dim, 1)), requires_grad=True)
+        self.drop_prob = drop_prob
+
+    def sample_keep(self, batch, device):
+        """floor(keep_prob + U[0,1)) / keep_prob per sample (blocks.py:1403-1409); None when inactive."""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep_prob = 1 - self.drop_prob
+        m = (keep_prob + torch.rand((batch,), dtype=torch.float32, device=device)).floor_()
+        return m / keep_prob
+
+
+class _MHCABase(nn.Module):
+    """Shared parameter set + dataflow of MaskedMHCA / MaskedMMHCA / LocalMaskedMHCA /
+    LocalMaskedMMHCA (blocks.py:199-313, 317-437, 441-781, 883-1224): depthwise k3 conv (+mask)
+    -> LayerNorm for q, k, v; 1x1 projections; attention core; 1x1 output projection (+mask).
+    window_size <= 1 selects the global core."""
+
+    def __init__(self, n_embd, n_head, window_size=-1, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0,
+                 proj_pdrop=0.0, use_rel_pe=False, use_time_weight=False):
+        super().__init__()
+        assert n_embd % n_head == 0
+        assert not use_rel_pe and not use_time_weight, "rel_pe / time_weight are off in every shipped config"
+        assert attn_pdrop == 0.0 and proj_pdrop == 0.0, "dropout inside attention is 0 in every shipped config"
+        assert (n_qx_stride == 1) or (n_qx_stride % 2 == 0)
+        assert (n_kv_stride == 1) or (n_kv_stride % 2 == 0)
+        assert n_qx_stride in (1, 2) and n_kv_stride in (1, 2)
+        self.n_embd, self.n_head = n_embd, n_head
+        self.n_channels = n_embd // n_head
+        self.scale = 1.0 / math.sqrt(self.n_channels)
+        self.window_size = window_size
+        self.window_overlap = window_size // 2
+        self.n_qx_stride, self.n_kv_stride = n_qx_stride, n_kv_stride
+        # NB the query conv uses the kv stride too (blocks.py:240,492,934) -- kept
+        stride = n_kv_stride
+        self.query_conv = MaskedConv1D(n_embd, n_embd, 3, stride=stride, padding=1, groups=n_embd, bias=False)
+        self.query_norm = LayerNorm(n_embd)
+        self.key_conv = MaskedConv1D(n_embd, n_embd, 3, stride=stride, padding=1, groups=n_embd, bias=False)
+        self.key_norm = LayerNorm(n_embd)
+        self.value_conv = MaskedConv1D(n_embd, n_embd, 3, stride=stride, padding=1, groups=n_embd, bias=False)
+        self.value_norm = LayerNorm(n_embd)
+        self.key = nn.Conv1d(n_embd, n_embd, 1)
+        self.query = nn.Conv1d(n_embd, n_embd, 1)
+        self.value = nn.Conv1d(n_embd, n_embd, 1)
+        self.proj = nn.Conv1d(n_embd, n_embd, 1)
+
+    def _attend(self, x_q, mask_q, x_k, mask_k, x_v, mask_v):
+        q, qx_mask = self.query_conv(x_q, mask_q)
+        q = self.query_norm(q)
+        k, kv_mask = self.key_conv(x_k, mask_k)
+        k = self.key_norm(k)
+        v, _ = self.value_conv(x_v, mask_v)
+        v = self.value_norm(v)
+        q = ops.conv1d(q, self.query.weight, self.query.bias)
+        k = ops.conv1d(k, self.key.weight, self.key.bias)
+        v = ops.conv1d(v, self.value.weight, self.value.bias)
+        if self.window_size > 1:
+            out = ops.local_attention(q, k, v, kv_mask, self.n_head, self.window_size)
+        else:
+            out = ops.global_attention(q, k, v, kv_mask, self.n_head)
+        out = ops.conv1d(out, self.proj.weight, self.proj.bias, qx_mask)
+        return out, qx_mask
+
+
+class MaskedMHCA(_MHCABase):
+    def __init__(self, n_embd, n_head, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0):
+        super().__init__(n_embd, n_head, -1, n_qx_stride, n_kv_stride, attn_pdrop, proj_pdrop)
+
+    def forward(self, x, mask):
+        return self._attend(x, mask, x, mask, x, mask)
+
+
+class LocalMaskedMHCA(_MHCABase):
+    def __init__(self, n_embd, n_head, window_size, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0,
+                 use_rel_pe=False, use_time_weight=False):
+        assert window_size > 1 and n_head >= 1
+        super().__init__(n_embd, n_head, window_size, n_qx_stride, n_kv_stride, attn_pdrop, proj_pdrop, use_rel_pe,
+                         use_time_weight)
+
+    def forward(self, x, mask):
+        return self._attend(x, mask, x, mask, x, mask)
+
+
+class MaskedMMHCA(_MHCABase):
+    def __init__(self, n_embd, n_head, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0):
+        super().__init__(n_embd, n_head, -1, n_qx_stride, n_kv_stride, attn_pdrop, proj_pdrop)
+
+    def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None):
+        x_k, mask_k = (x_q, mask_q) if x_k is None else (x_k, mask_k)
+        x_v, mask_v = (x_q, mask_q) if x_v is None else (x_v, mask_v)
+        return self._attend(x_q, mask_q, x_k, mask_k, x_v, mask_v)
+
+
+class LocalMaskedMMHCA(_MHCABase):
+    def __init__(self, n_embd, n_head, window_size, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0,
+                 use_rel_pe=False, use_time_weight=False):
+        assert window_size > 1 and n_head >= 1
+        super().__init__(n_embd, n_head, window_size, n_qx_stride, n_kv_stride, attn_pdrop, proj_pdrop, use_rel_pe,
+                         use_time_weight)
+
+    def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None):
+        assert x_k is not None and x_v is not None, "every call site passes k and v (backbones.py:467,487,490)"
+        return self._attend(x_q, mask_q, x_k, mask_k, x_v, mask_v)
+
+
+class _BlockBase(nn.Module):
+    def _build_common(self, n_embd, n_head, n_ds_strides, n_out, n_hidden, proj_pdrop, path_pdrop):
+        assert len(n_ds_strides) == 2
+        assert proj_pdrop == 0.0, "train_cfg['dropout'] is 0 in every shipped config"
+        self.stride = n_ds_strides[0]
+        assert self.stride in (1, 2), "pool_skip is MaxPool1d(3, 2, 1) for stride 2 (blocks.py:1277-1281)"
+        self.pool_skip = nn.Identity()     # parameter-free; the max-pool runs in the HIP kernel
+        n_hidden = 4 * n_embd if n_hidden is None else n_hidden
+        n_out = n_embd if n_out is None else n_out
+        self.mlp = nn.Sequential(nn.Conv1d(n_embd, n_hidden, 1), nn.GELU(), nn.Dropout(proj_pdrop, inplace=True),
+                                 nn.Conv1d(n_hidden, n_out, 1), nn.Dropout(proj_pdrop, inplace=True))
+        if path_pdrop > 0.0:
+            self.drop_path_attn = AffineDropPath(n_embd, drop_prob=path_pdrop)
+            self.drop_path_mlp = AffineDropPath(n_out, drop_prob=path_pdrop)
+        else:
+            self.drop_path_attn = nn.Identity()
+            self.drop_path_mlp = nn.Identity()
+            self.register_buffer("_ones", torch.ones(n_embd), persistent=False)
+
+    def _residual_mlp(self, x, out, out_mask):
+        """blocks.py:1311-1313 / 870-872: skip*mask + dp(attn); then + dp(mlp(ln2(.))*mask)."""
+        B = x.shape[0]
+        skip = ops.maxpool3s2(x) if self.stride > 1 else x
+        if isinstance(self.drop_path_attn, AffineDropPath):
+            sa, ka = self.drop_path_attn.scale, self.drop_path_attn.sample_keep(B, x.device)
+            sm, km = self.drop_path_mlp.scale, self.drop_path_mlp.sample_keep(B, x.device)
+        else:
+            sa = sm = self._ones
+            ka = km = None
+        out = ops.affine_residual(skip, out_mask, out, None, sa, ka)
+        h = self.ln2(out)
+        h = ops.conv1d(h, self.mlp[0].weight, self.mlp[0].bias, None, 1, ops.ACT_GELU)
+        h = ops.conv1d(h, self.mlp[3].weight, self.mlp[3].bias, out_mask)
+        return ops.affine_residual(out, None, h, None, sm, km)
+
+
+class TransformerBlock(_BlockBase):
+    """Pre-LN block with (local) conv attention (blocks.py:1227-1317)."""
+
+    def __init__(self, n_embd, n_head, n_ds_strides=(1, 1), n_out=None, n_hidden=None, act_layer=nn.GELU,
+                 attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, mha_win_size=-1, use_rel_pe=False,
+                 use_time_weight=False):
+        super().__init__()
+        assert act_layer is nn.GELU
+        self.ln1 = LayerNorm(n_embd)
+        self.ln2 = LayerNorm(n_embd)
+        if mha_win_size > 1:
+            self.attn = LocalMaskedMHCA(n_embd, n_head, window_size=mha_win_size, n_qx_stride=n_ds_strides[0],
+                                        n_kv_stride=n_ds_strides[1], attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop,
+                                        use_rel_pe=use_rel_pe, use_time_weight=use_time_weight)
+        else:
+            self.attn = MaskedMHCA(n_embd, n_head, n_qx_stride=n_ds_strides[0], n_kv_stride=n_ds_strides[1],
+                                   attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop)
+        self._build_common(n_embd, n_head, n_ds_strides, n_out, n_hidden, proj_pdrop, path_pdrop)
+
+    def forward(self, x, mask, pos_embd=None):
+        assert pos_embd is None
+        out, out_mask = self.attn(self.ln1(x), mask)
+        return self._residual_mlp(x, out, out_mask), out_mask
+
+
+class MutilModelTransformerBlock(_BlockBase):
+    """Cross-modal block: q from x_q, k from x_k, v from x_v (blocks.py:783-876)."""
+
+    def __init__(self, n_embd, n_head, n_ds_strides=(1, 1), n_out=None, n_hidden=None, act_layer=nn.GELU,
+                 attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, mha_win_size=-1, use_rel_pe=False,
+                 use_time_weight=False):
+        super().__init__()
+        assert act_layer is nn.GELU
+        self.lnq = LayerNorm(n_embd)
+        self.lnk = LayerNorm(n_embd)
+        self.lnv = LayerNorm(n_embd)
+        self.ln2 = LayerNorm(n_embd)
+        if mha_win_size > 1:
+            self.attn = LocalMaskedMMHCA(n_embd, n_head, window_size=mha_win_size, n_qx_stride=n_ds_strides[0],
+                                         n_kv_stride=n_ds_strides[1], attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop,
+                                         use_rel_pe=use_rel_pe, use_time_weight=use_time_weight)
+        else:
+            self.attn = MaskedMMHCA(n_embd, n_head, n_qx_stride=n_ds_strides[0], n_kv_stride=n_ds_strides[1],
+                                    attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop)
+        self._build_common(n_embd, n_head, n_ds_strides, n_out, n_hidden, proj_pdrop, path_pdrop)
+
+    def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None, pos_embd=None):
+        assert pos_embd is None
+        out, out_mask = self.attn(self.lnq(x_q), mask_q, self.lnk(x_k), mask_k, self.lnv(x_v), mask_v)
+        return self._residual_mlp(x_q, out, out_mask), out_mask
+
+
+class DownBlock(nn.Module):
+    """masked conv k3 (stride 2 by default) -> InstanceNorm1d -> LeakyReLU(0.2) (blocks.py:1495-1516)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size=3, stride=2, padding=1, dilation=1, norm=True):
+        super().__init__()
+        self.conv_block = MaskedConv1D(in_channel, out_channel, kernel_size, stride=stride, padding=padding,
+                                       dilation=dilation)
+        self.norm = norm
+        assert norm, "every shipped config builds DownBlock with norm=True"
+
+    def forward(self, x, mask):
+        x, mask = self.conv_block(x, mask)
+        return ops.instnorm_lrelu(x, 1e-5, 0.2), mask
+
+
+class MaskedConvTranspose1D(nn.Module):
+    """Parameter holder of the Expansion branch (blocks.py:1443-1491).  Its output is discarded by
+    the exp10/exp12 meta-arch (av_fd_no_recon.py:346-349), so no kernel is attached yet."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
+                 groups=1, padding_mode='zeros'):
+        super().__init__()
+        assert (kernel_size % 2 == 1) and (kernel_size // 2 == padding)
+        self.stride = stride
+        self.conv = nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride, padding,
+                                       output_padding=output_padding, dilation=dilation, groups=groups,
+                                       padding_mode=padding_mode)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size=3, padding=1, stride=2, dilation=1, output_padding=0,
+                 norm=True, last=False):
+        super().__init__()
+        self.conv_transpose = MaskedConvTranspose1D(in_channel, out_channel, kernel_size, stride=stride,
+                                                    padding=padding, dilation=dilation, output_padding=output_padding)
+        self.norm, self.last = norm, last
+
+
+class Contraction(nn.Module):
+    def __init__(self, in_channels, out_channels, hidden_dims=256):
+        super().__init__()
+        self.down_1 = DownBlock(in_channels, hidden_dims)
+        self.down_2 = DownBlock(hidden_dims, hidden_dims * 2)
+        self.down_3 = DownBlock(hidden_dims * 2, hidden_dims * 4)
+        self.down_4 = DownBlock(hidden_dims * 4, hidden_dims * 8)
+        self.down_5 = DownBlock(hidden_dims * 8, out_channels)
+
+    def forward(self, x, mask):
+        for blk in (self.down_1, self.down_2, self.down_3, self.down_4, self.down_5):
+            x, mask = blk(x, mask)
+        return x, mask
+
+
+class Expansion(nn.Module):
+    def __init__(self, in_channels, out_channels, hidden_dims=2048, tanh=True):
+        super().__init__()
+        self.up_1 = UpBlock(in_channels, hidden_dims, output_padding=1)
+        self.up_2 = UpBlock(hidden_dims, hidden_dims // 2, output_padding=1)
+        self.up_3 = UpBlock(hidden_dims // 2, hidden_dims // 4, output_padding=1)
+        self.up_4 = UpBlock(hidden_dims // 4, hidden_dims // 8, output_padding=1)
+        self.up_5 = UpBlock(hidden_dims // 8, out_channels, output_padding=1, last=tanh)
+
+
+class DeepInterpolator(nn.Module):
+    """Contraction -> video-level classifier (blocks.py:1593-1638).  `norm=False` is the only mode the
+    shipped meta-archs use (av_fd_no_recon.py:317).  The Expansion parameters exist for state-dict
+    parity; its (unused) output is not computed."""
+
+    def __init__(self, in_channels, hidden_channels=512, num_classes=1, norm=True):
+        super().__init__()
+        assert not norm, "normalize_batch is disabled by every shipped meta-arch"
+        self.norm = norm
+        self.contraction = Contraction(in_channels, hidden_channels)
+        self.expansion = Expansion(hidden_channels, in_channels, tanh=False)
+        self.conv0 = nn.Sequential(nn.Conv1d(hidden_channels, hidden_channels, kernel_size=1, bias=False),
+                                   nn.InstanceNorm1d(hidden_channels), nn.LeakyReLU(0.2))
+        self.conv1 = nn.Linear(hidden_channels * 2, hidden_channels, bias=False)
+        self.conv2 = nn.Linear(hidden_channels, num_classes)
+        self.bn1 = LayerNorm(hidden_channels)
+        self.dp1 = nn.Dropout(p=0.5)
+
+    def classifier(self, x):
+        """blocks.py:1608-1618 on time-major [B, T, H] features -> [B, num_classes]."""
+        B = x.shape[0]
+        x = ops.conv1d(x, self.conv0[0].weight)
+        x = ops.instnorm_lrelu(x, 1e-5, 0.2)
+        pooled = ops.maxavgpool(x)                                   # [B, 2H] = cat(max, avg)
+        h = ops.linear(pooled, self.conv1.weight)
+        h = self.bn1(h, relu=True)
+        if self.training and self.dp1.p > 0:
+            keep = (torch.rand_like(h) >= self.dp1.p).to(h.dtype) / (1.0 - self.dp1.p)
+            h = ops.scale_rows(h.reshape(-1, 1), keep.reshape(-1)).view_as(h)
+        w = self.conv2.weight
+        return ops.smallconv(h.view(B, 1, -1), w.view(w.shape[0], w.shape[1], 1), self.conv2.bias).view(B, -1)
+
+    def forward(self, inputs, mask):
+        feat, _ = self.contraction(inputs, mask)
+        return self.classifier(feat)

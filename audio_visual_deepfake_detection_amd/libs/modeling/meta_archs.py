@@ -1,0 +1,290 @@
+"""Audio-visual temporal-localisation meta-architecture on MI355X.
+
+Drop-in for the reference's `AVLocPointTransformerRecoveryNoNormNorecon`
+(libs/modeling/av_fd_no_recon.py:162-876): same constructor kwargs, same state-dict keys, same
+`forward(video_list)` contract (training: dict of losses incl. 'final_loss'; eval: list of result
+dicts with CPU tensors in seconds).  Everything between the H2D copy and the final D2H copy runs in
+hand-written gfx950 kernels on time-major tensors.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .models import register_meta_arch, make_backbone, make_neck, make_generator
+from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator
+from ... import ops
+
+
+class PtTransformerClsHead(nn.Module):
+    """Shared classification head (av_fd_no_recon.py:13-89): 2 x [conv k3 -> LN -> ReLU] -> conv k3."""
+
+    def __init__(self, input_dim, feat_dim, num_classes, prior_prob=0.01, num_layers=3, kernel_size=3,
+                 act_layer=nn.ReLU, with_ln=False, empty_cls=[]):
+        super().__init__()
+        assert with_ln and act_layer is nn.ReLU and kernel_size == 3
+        self.head, self.norm = nn.ModuleList(), nn.ModuleList()
+        for idx in range(num_layers - 1):
+            self.head.append(MaskedConv1D(input_dim if idx == 0 else feat_dim, feat_dim, kernel_size, stride=1,
+                                          padding=kernel_size // 2, bias=(not with_ln)))
+            self.norm.append(LayerNorm(feat_dim))
+        self.cls_head = MaskedConv1D(feat_dim, num_classes, kernel_size, stride=1, padding=kernel_size // 2)
+        if prior_prob > 0:
+            torch.nn.init.constant_(self.cls_head.conv.bias, -(math.log((1 - prior_prob) / prior_prob)))
+        if len(empty_cls) > 0:
+            for idx in empty_cls:
+                torch.nn.init.constant_(self.cls_head.conv.bias[idx], -(math.log((1 - 1e-6) / 1e-6)))
+
+    def forward(self, fpn_feats, fpn_masks):
+        assert len(fpn_feats) == len(fpn_masks)
+        out = tuple()
+        for feat, mask in zip(fpn_feats, fpn_masks):
+            cur = feat
+            for idx in range(len(self.head)):
+                cur, _ = self.head[idx](cur, mask)
+                cur = self.norm[idx](cur, relu=True)
+            out += (ops.smallconv(cur, self.cls_head.conv.weight, self.cls_head.conv.bias, mask),)   # [B,T_l,nc]
+        return out
+
+
+class PtTransformerRegHead(nn.Module):
+    """Shared regression head (av_fd_no_recon.py:92-159); the per-level Scale and the final ReLU are
+    fused into the narrow-conv kernel."""
+
+    def __init__(self, input_dim, feat_dim, fpn_levels, num_layers=3, kernel_size=3, act_layer=nn.ReLU,
+                 with_ln=False):
+        super().__init__()
+        assert with_ln and act_layer is nn.ReLU and kernel_size == 3
+        self.fpn_levels = fpn_levels
+        self.head, self.norm = nn.ModuleList(), nn.ModuleList()
+        for idx in range(num_layers - 1):
+            self.head.append(MaskedConv1D(input_dim if idx == 0 else feat_dim, feat_dim, kernel_size, stride=1,
+                                          padding=kernel_size // 2, bias=(not with_ln)))
+            self.norm.append(LayerNorm(feat_dim))
+        self.scale = nn.ModuleList([Scale() for _ in range(fpn_levels)])
+        self.offset_head = MaskedConv1D(feat_dim, 2, kernel_size, stride=1, padding=kernel_size // 2)
+
+    def forward(self, fpn_feats, fpn_masks):
+        assert len(fpn_feats) == len(fpn_masks) == self.fpn_levels
+        out = tuple()
+        for l, (feat, mask) in enumerate(zip(fpn_feats, fpn_masks)):
+            cur = feat
+            for idx in range(len(self.head)):
+                cur, _ = self.head[idx](cur, mask)
+                cur = self.norm[idx](cur, relu=True)
+            out += (ops.smallconv(cur, self.offset_head.conv.weight, self.offset_head.conv.bias, mask,
+                                  self.scale[l].scale),)                                              # [B,T_l,2]
+        return out
+
+
+@register_meta_arch("AVLocPointTransformerRecoveryNoNormNorecon")
+class AVPtTransformerRecovery(nn.Module):
+    """exp10 / exp12 model (configs_train/deepfake_exp10.yaml, configs_test/deepfake_exp12_test.yaml)."""
+
+    def __init__(self, backbone_type, fpn_type, backbone_arch, scale_factor, video_input_dim, audio_input_dim,
+                 max_seq_len, max_buffer_len_factor, n_head, n_mha_win_size, embd_kernel_size, embd_dim, embd_with_ln,
+                 fpn_dim, fpn_with_ln, fpn_start_level, head_dim, regression_range, head_num_layers,
+                 head_kernel_size, head_with_ln, use_abs_pe, use_rel_pe, num_classes, train_cfg, test_cfg,
+                 mlp_ratio=None):
+        super().__init__()
+        input_dim = video_input_dim + audio_input_dim
+        self.input_dim = input_dim
+        self.fpn_strides = [scale_factor ** i for i in range(fpn_start_level, backbone_arch[-1] + 1)]
+        self.reg_range = regression_range
+        assert len(self.fpn_strides) == len(self.reg_range)
+        self.scale_factor = scale_factor
+        self.num_classes = num_classes
+        assert num_classes == 1, "the deepfake datasets are single-class (deepfake_video_audio.py:1536)"
+        self.max_seq_len = max_seq_len
+        if isinstance(n_mha_win_size, int):
+            self.mha_win_size = [n_mha_win_size] * (1 + backbone_arch[-1])
+        else:
+            assert len(n_mha_win_size) == (1 + backbone_arch[-1])
+            self.mha_win_size = n_mha_win_size
+        max_div_factor = 1
+        for s, w in zip(self.fpn_strides, self.mha_win_size):
+            stride = s * (w // 2) * 2 if w > 1 else s
+            assert max_seq_len % stride == 0, "max_seq_len must be divisible by fpn stride and window size"
+            max_div_factor = max(max_div_factor, stride)
+        self.max_div_factor = max_div_factor
+        self.mlp_ratio = mlp_ratio
+
+        self.train_center_sample = train_cfg['center_sample']
+        assert self.train_center_sample in ['radius', 'none']
+        self.train_center_sample_radius = train_cfg['center_sample_radius']
+        self.train_loss_weight = train_cfg['loss_weight']
+        assert self.train_loss_weight > 0, "auto-balanced loss weight (<=0) is unused by the shipped configs"
+        self.train_cls_prior_prob = train_cfg['cls_prior_prob']
+        self.train_dropout = train_cfg['dropout']
+        self.train_droppath = train_cfg['droppath']
+        self.train_label_smoothing = train_cfg['label_smoothing']
+
+        self.test_pre_nms_thresh = test_cfg['pre_nms_thresh']
+        self.test_pre_nms_topk = test_cfg['pre_nms_topk']
+        self.test_iou_threshold = test_cfg['iou_threshold']
+        self.test_min_score = test_cfg['min_score']
+        self.test_max_seg_num = test_cfg['max_seg_num']
+        self.test_nms_method = test_cfg['nms_method']
+        assert self.test_nms_method in ['soft', 'hard', 'none']
+        self.test_duration_thresh = test_cfg['duration_thresh']
+        self.test_multiclass_nms = test_cfg['multiclass_nms']
+        self.test_nms_sigma = test_cfg['nms_sigma']
+        self.test_voting_thresh = test_cfg['voting_thresh']
+
+        assert backbone_type in ['convHRLRFullResSelfAttTransformerRevised']
+        self.backbone = make_backbone(backbone_type, **{
+            'n_in': input_dim, 'n_embd': embd_dim, 'n_head': n_head, 'n_embd_ks': embd_kernel_size,
+            'max_len': max_seq_len, 'arch': backbone_arch, 'mha_win_size': self.mha_win_size,
+            'scale_factor': scale_factor, 'with_ln': embd_with_ln, 'attn_pdrop': 0.0,
+            'proj_pdrop': self.train_dropout, 'path_pdrop': self.train_droppath, 'use_abs_pe': use_abs_pe,
+            'use_rel_pe': use_rel_pe})
+        if isinstance(embd_dim, (list, tuple)):
+            embd_dim = sum(embd_dim)
+        assert fpn_type in ['fpn', 'identity']
+        self.neck = make_neck(fpn_type, **{
+            'in_channels': [embd_dim] * (backbone_arch[-1] + 1), 'out_channel': fpn_dim,
+            'scale_factor': scale_factor, 'start_level': fpn_start_level, 'with_ln': fpn_with_ln})
+        self.point_generator = make_generator('point', **{
+            'max_seq_len': max_seq_len * max_buffer_len_factor, 'fpn_strides': self.fpn_strides,
+            'regression_range': self.reg_range})
+        self.cls_head = PtTransformerClsHead(fpn_dim, head_dim, self.num_classes, kernel_size=head_kernel_size,
+                                             prior_prob=self.train_cls_prior_prob, with_ln=head_with_ln,
+                                             num_layers=head_num_layers, empty_cls=train_cfg['head_empty_cls'])
+        self.reg_head = PtTransformerRegHead(fpn_dim, head_dim, len(self.fpn_strides), kernel_size=head_kernel_size,
+                                             num_layers=head_num_layers, with_ln=head_with_ln)
+        self.interpolator = DeepInterpolator(input_dim, embd_dim, norm=False)
+
+        # EMA of #foreground (av_fd_no_recon.py:321-322).  Kept on the device so a training step has no
+        # host sync; `loss_normalizer` (python float in the reference) is exposed as a property.
+        self.loss_normalizer_momentum = 0.9
+        self.register_buffer("_loss_norm_state", torch.tensor([float(train_cfg['init_loss_norm'])]),
+                             persistent=False)
+        self.video_loss_weight = 0.1            # av_fd_no_recon.py:702
+        self.num_pos_hook = None                # data-parallel: all-reduce of the positive count
+        self.max_gt_per_clip = 16
+        self.last_debug = {}
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def loss_normalizer(self):
+        return float(self._loss_norm_state.item())
+
+    @loss_normalizer.setter
+    def loss_normalizer(self, v):
+        self._loss_norm_state.fill_(float(v))
+
+    @property
+    def device(self):
+        return list(set(p.device for p in self.parameters()))[0]
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def preprocessing(self, video_list, padding_val=0.0):
+        """av_fd_no_recon.py:431-479, producing TIME-MAJOR device tensors: x [B, T, C], mask fp32 [B, T].
+
+        Each item carries either the reference's 'feats' ([C, T_i] fp32, CPU or device) or the fast-path
+        'feats_tm' ([T_i, C] fp32 already on the device, e.g. from the K1 interpolation kernel).
+        """
+        dev = self.device
+        assert dev.type == "cuda", "the MI355X path needs the model on a HIP device (no CPU fallback)"
+        tm = 'feats_tm' in video_list[0]
+        lens = [int(v['feats_tm'].shape[0] if tm else v['feats'].shape[-1]) for v in video_list]
+        max_len = max(lens)
+        if self.training:
+            assert max_len <= self.max_seq_len, "Input length must be smaller than max_seq_len during training"
+            max_len = self.max_seq_len
+        else:
+            assert len(video_list) == 1 or getattr(self, "allow_batched_eval", False), \
+                "Only support batch_size = 1 during inference"
+            assert max_len <= self.max_seq_len, \
+                "force_upsampling keeps T <= max_seq_len; longer inputs are not supported on the HIP path yet"
+            max_len = self.max_seq_len
+        B, C = len(video_list), self.input_dim
+        if tm:
+            x = torch.full((B, max_len, C), padding_val, dtype=torch.float32, device=dev)
+            for b, v in enumerate(video_list):
+                x[b, :lens[b]].copy_(v['feats_tm'])
+        else:
+            ct = video_list[0]['feats'].new_full((B, C, max_len), padding_val)
+            for b, v in enumerate(video_list):
+                ct[b, :, :lens[b]].copy_(v['feats'])
+            x = ops.transpose_last2(ct.to(dev, non_blocking=True))         # [B,C,T] -> [B,T,C] on device
+        mask = (torch.arange(max_len)[None, :] < torch.as_tensor(lens)[:, None]).to(torch.float32).to(dev)
+        return x, mask
+
+    # ------------------------------------------------------------------------------------------
+    def forward_features(self, x, mask):
+        """Network body on time-major tensors: returns (logits [B,P], offsets [B,P,2], pmask [B,P],
+        video logits [B,1], per-level lengths)."""
+        cls_scores = self.interpolator(x, mask)
+        feats, masks = self.backbone(x, None, mask)
+        fpn_feats, fpn_masks = self.neck(feats, masks)
+        out_cls = self.cls_head(fpn_feats, fpn_masks)
+        out_off = self.reg_head(fpn_feats, fpn_masks)
+        logits = torch.cat([c.squeeze(-1) for c in out_cls], dim=1)
+        offsets = torch.cat(out_off, dim=1)
+        pmask = torch.cat(fpn_masks, dim=1)
+        return logits, offsets, pmask, cls_scores, [int(f.shape[1]) for f in fpn_feats]
+
+    def forward(self, video_list):
+        x, mask = self.preprocessing(video_list)
+        logits, offsets, pmask, cls_scores, lens = self.forward_features(x, mask)
+        points = torch.cat(self.point_generator(lens), dim=0)
+        if self.training:
+            gt, ngt = self._pack_gt(video_list, x.device)
+            return self.losses(points, logits, offsets, pmask, cls_scores, gt, ngt)
+        return self.inference(video_list, points, pmask, logits, offsets, cls_scores, lens)
+
+    # ------------------------------------------------------------------------------------------
+    def _pack_gt(self, video_list, dev):
+        """`segments is None` marks a real clip (av_fd_no_recon.py:388-395): ngt = 0."""
+        G = max([self.max_gt_per_clip] + [0 if v['segments'] is None else int(v['segments'].shape[0])
+                                         for v in video_list])
+        gt = torch.zeros((len(video_list), G, 2), dtype=torch.float32)
+        ngt = torch.zeros((len(video_list),), dtype=torch.int32)
+        for b, v in enumerate(video_list):
+            if v['segments'] is not None:
+                n = int(v['segments'].shape[0])
+                assert n > 0, "a fake clip must carry at least one segment"
+                gt[b, :n] = v['segments'].to(torch.float32)
+                ngt[b] = n
+        return gt.to(dev), ngt.to(dev)
+
+    def losses(self, points, logits, offsets, pmask, cls_scores, gt, ngt):
+        """label_points + losses (av_fd_no_recon.py:481-707) in two fused kernels."""
+        cfg = (float(self.train_center_sample_radius), self.train_center_sample == 'radius',
+               float(self.train_label_smoothing), float(self.train_loss_weight), float(self.video_loss_weight),
+               float(self.loss_normalizer_momentum))
+        out = ops.loc_losses(logits, offsets, cls_scores.reshape(-1), points, pmask, gt, ngt,
+                             self._loss_norm_state, cfg, self.num_pos_hook)
+        det = out.detach()
+        self.last_debug['num_pos'] = det[4]
+        return {'cls_loss': det[0], 'reg_loss': det[1], 'reco_cls_loss': det[2], 'final_loss': out[3]}
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, video_list, points, pmask, logits, offsets, cls_scores, lens):
+        """decode + NMS + voting on the device (av_fd_no_recon.py:709-825, nms.py), then the
+        seconds conversion of postprocessing (av_fd_no_recon.py:827-876) on the host."""
+        assert self.test_nms_method == 'hard' and not self.test_multiclass_nms, \
+            "only the class-agnostic hard-NMS branch used by the shipped configs is implemented"
+        assert self.test_pre_nms_topk >= max(lens), \
+            "per-level top-k below the level length is not implemented (pre_nms_topk is 2000-5000 in every config)"
+        segs, scores, pidx, count = ops.decode_nms(
+            points, logits, offsets, pmask, float(self.test_pre_nms_thresh), float(self.test_duration_thresh),
+            float(self.test_min_score), float(self.test_iou_threshold), float(self.test_voting_thresh),
+            int(self.test_max_seg_num))
+        segs, scores, pidx, count = segs.cpu(), scores.cpu(), pidx.cpu(), count.cpu()
+        video_cls = cls_scores.detach().cpu()
+        results = []
+        for b, v in enumerate(video_list):
+            n = int(count[b])
+            s, sc = segs[b, :n].clone(), scores[b, :n].clone()
+            if n > 0:
+                s = (s * v['feat_stride'] + 0.5 * v['feat_num_frames']) / v['fps']
+                s[s <= 0.0] *= 0.0
+                s[s >= v['duration']] = s[s >= v['duration']] * 0.0 + v['duration']
+            results.append({'video_id': v['video_id'], 'segments': s, 'scores': sc,
+                            'labels': torch.zeros(n, dtype=torch.int64), 'video_cls': video_cls[b],
+                            'kept_points': pidx[b, :n].to(torch.int64)})
+        return results

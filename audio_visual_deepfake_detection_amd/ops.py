@@ -1,0 +1,559 @@
+"""PyTorch-ROCm custom ops over the C ABI of libavdf_hip.so.
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the HIP stream and the
+autograd tape.  Every op below launches hand-written gfx950 kernels through ctypes; there is no
+eager/aten fallback -- a CPU tensor or a missing library raises.
+
+Layout: activations time-major [B, T, C] fp32; masks fp32 [B, T]; weights in the reference
+layouts (Conv1d [Cout, Cin/groups, K], LayerNorm [1, C, 1], ...).
+"""
+import torch
+
+from ._lib import lib, check
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    """Device pointer of a contiguous fp32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("avdf ops need HIP (cuda) tensors: there is no CPU fallback")
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise RuntimeError(f"avdf ops need float32/int32 tensors, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("avdf ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _ws(n, like):
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=like.device)
+
+
+def _acc_or_new(ctx_needs, shape_like):
+    return torch.empty_like(shape_like) if ctx_needs else None
+
+
+# --------------------------------------------------------------------------------------------
+# dense conv1d (implicit GEMM, exact-fp32 MFMA)
+# --------------------------------------------------------------------------------------------
+class Conv1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, mask, stride, act):
+        x, w, bias, mask = _c(x), _c(w), _c(bias), _c(mask)
+        B, Tin, Cin = x.shape
+        Cout, Cin_w, K = w.shape
+        assert Cin_w == Cin, (w.shape, x.shape)
+        assert Tin % stride == 0, "input length must be divisible by stride"   # blocks.py:46
+        Tout = (Tin + 2 * (K // 2) - K) // stride + 1
+        y = torch.empty((B, Tout, Cout), dtype=x.dtype, device=x.device)
+        need_pre = act != ACT_NONE and any(ctx.needs_input_grad)
+        ypre = torch.empty_like(y) if need_pre else None
+        check(lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
+                                  K, stride, act, _stream()), "conv1d_fwd")
+        ctx.save_for_backward(x, w, mask, ypre)
+        ctx.cfg = (B, Tin, Cin, Tout, Cout, K, stride, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mask, ypre = ctx.saved_tensors
+        B, Tin, Cin, Tout, Cout, K, stride, act, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = db = None
+        st = _stream()
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.avdf_conv1d_bwd_data(_p(dy), _p(w), _p(mask), _p(ypre), _p(dx), B, Tin, Cin, Tout, Cout,
+                                           K, stride, act, st), "conv1d_bwd_data")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, dtype=w.dtype, device=w.device) if has_bias else None
+            ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K), x)
+            check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws), B, Tin, Cin,
+                                             Tout, Cout, K, stride, act, 0, st), "conv1d_bwd_weight")
+        return dx, dw, db, None, None, None
+
+
+def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE):
+    return Conv1dFn.apply(x, w, bias, mask, stride, act)
+
+
+def linear(x2d, w, bias=None, act=ACT_NONE):
+    """nn.Linear on [M, Cin] rows via the K=1 conv path (weight [out, in])."""
+    M, Cin = x2d.shape
+    y = conv1d(x2d.view(1, M, Cin), w.view(w.shape[0], Cin, 1), bias, None, 1, act)
+    return y.view(M, w.shape[0])
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm over channels
+# --------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, pe, mask):
+        x = _c(x)
+        shp = x.shape
+        C = shp[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        need = any(ctx.needs_input_grad)
+        mean = torch.empty(M, dtype=x.dtype, device=x.device) if need else None
+        rstd = torch.empty(M, dtype=x.dtype, device=x.device) if need else None
+        T = shp[-2] if pe is not None else 0
+        g = None if gamma is None else gamma.contiguous().view(-1)
+        b = None if beta is None else beta.contiguous().view(-1)
+        check(lib.avdf_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, C, eps, int(relu),
+                                     _p(_c(pe)), _p(_c(mask)), T, _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, g, b, mean, rstd)
+        ctx.cfg = (M, C, int(relu), None if gamma is None else gamma.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, rstd = ctx.saved_tensors
+        M, C, relu, gshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=x.dtype, device=x.device) if g is not None else None
+        db = torch.empty(C, dtype=x.dtype, device=x.device) if g is not None else None
+        ws = _ws(lib.avdf_layernorm_bwd_ws(M, C), x)
+        check(lib.avdf_layernorm_bwd(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
+                                     M, C, relu, 0, _stream()), "layernorm_bwd")
+        if dg is not None:
+            dg, db = dg.view(gshape), db.view(gshape)
+        return dx, dg, db, None, None, None, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, pe=None, mask=None):
+    return LayerNormFn.apply(x, gamma, beta, eps, relu, pe, mask)
+
+
+# --------------------------------------------------------------------------------------------
+# depthwise conv k3
+# --------------------------------------------------------------------------------------------
+class DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, mask, stride):
+        x, w, mask = _c(x), _c(w), _c(mask)
+        B, Tin, C = x.shape
+        assert w.shape == (C, 1, 3), w.shape
+        assert Tin % stride == 0, "input length must be divisible by stride"
+        Tout = (Tin - 1) // stride + 1
+        y = torch.empty((B, Tout, C), dtype=x.dtype, device=x.device)
+        check(lib.avdf_dwconv_fwd(_p(x), _p(w), _p(mask), _p(y), B, Tin, Tout, C, stride, _stream()), "dwconv_fwd")
+        ctx.save_for_backward(x, w, mask)
+        ctx.cfg = (B, Tin, Tout, C, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mask = ctx.saved_tensors
+        B, Tin, Tout, C, stride = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        ws = _ws(lib.avdf_dwconv_bwd_ws(B, Tout, C), x) if dw is not None else None
+        check(lib.avdf_dwconv_bwd(_p(dy), _p(x), _p(w), _p(mask), _p(dx), _p(dw), _p(ws), B, Tin, Tout, C, stride, 0,
+                                  _stream()), "dwconv_bwd")
+        return dx, dw, None, None
+
+
+def dwconv(x, w, mask=None, stride=1):
+    return DwConvFn.apply(x, w, mask, stride)
+
+
+# --------------------------------------------------------------------------------------------
+# attention cores
+# --------------------------------------------------------------------------------------------
+class LocalAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kvmask, n_head, window):
+        q, k, v, kvmask = _c(q), _c(k), _c(v), _c(kvmask)
+        B, T, C = q.shape
+        assert k.shape == q.shape and v.shape == q.shape, "local attention needs equal q/k/v lengths"
+        assert T % (2 * (window // 2)) == 0      # blocks.py:1060
+        hs = C // n_head
+        scale = 1.0 / (hs ** 0.5)
+        out = torch.empty_like(q)
+        need = any(ctx.needs_input_grad)
+        probs = torch.empty((B, T, n_head, window), dtype=q.dtype, device=q.device) if need else None
+        check(lib.avdf_local_attn_fwd(_p(q), _p(k), _p(v), _p(kvmask), _p(out), _p(probs), B, T, n_head, hs, window,
+                                      scale, _stream()), "local_attn_fwd")
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.cfg = (B, T, n_head, hs, window, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, probs = ctx.saved_tensors
+        B, T, H, hs, window, scale = ctx.cfg
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = _ws(lib.avdf_local_attn_bwd_ws(B, T, H, window), q)
+        check(lib.avdf_local_attn_bwd(_p(dout), _p(q), _p(k), _p(v), _p(probs), _p(dq), _p(dk), _p(dv), _p(ws),
+                                      B, T, H, hs, window, scale, _stream()), "local_attn_bwd")
+        return dq, dk, dv, None, None, None
+
+
+class GlobalAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kvmask, n_head):
+        q, k, v, kvmask = _c(q), _c(k), _c(v), _c(kvmask)
+        B, Tq, C = q.shape
+        Tk = k.shape[1]
+        hs = C // n_head
+        scale = 1.0 / (hs ** 0.5)
+        out = torch.empty_like(q)
+        need = any(ctx.needs_input_grad)
+        probs = torch.empty((B, n_head, Tq, Tk), dtype=q.dtype, device=q.device) if need else None
+        check(lib.avdf_global_attn_fwd(_p(q), _p(k), _p(v), _p(kvmask), _p(out), _p(probs), B, Tq, Tk, n_head, hs,
+                                       scale, _stream()), "global_attn_fwd")
+        ctx.save_for_backward(q, k, v, kvmask, probs)
+        ctx.cfg = (B, Tq, Tk, n_head, hs, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, kvmask, probs = ctx.saved_tensors
+        B, Tq, Tk, H, hs, scale = ctx.cfg
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = _ws(lib.avdf_global_attn_bwd_ws(B, Tq, Tk, H), q)
+        check(lib.avdf_global_attn_bwd(_p(dout), _p(q), _p(k), _p(v), _p(kvmask), _p(probs), _p(dq), _p(dk), _p(dv),
+                                       _p(ws), B, Tq, Tk, H, hs, scale, _stream()), "global_attn_bwd")
+        return dq, dk, dv, None, None
+
+
+def local_attention(q, k, v, kvmask, n_head, window):
+    return LocalAttnFn.apply(q, k, v, kvmask, n_head, window)
+
+
+def global_attention(q, k, v, kvmask, n_head):
+    return GlobalAttnFn.apply(q, k, v, kvmask, n_head)
+
+
+# --------------------------------------------------------------------------------------------
+# block glue
+# --------------------------------------------------------------------------------------------
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, Tin, C = x.shape
+        y = torch.empty((B, (Tin - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+        check(lib.avdf_maxpool3s2_fwd(_p(x), _p(y), B, Tin, C, _stream()), "maxpool_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, Tin, C = x.shape
+        dx = torch.empty_like(x)
+        check(lib.avdf_maxpool3s2_bwd(_p(dy.contiguous()), _p(x), _p(dx), B, Tin, C, _stream()), "maxpool_bwd")
+        return dx
+
+
+def maxpool3s2(x):
+    return MaxPoolFn.apply(x)
+
+
+class AffineResidualFn(torch.autograd.Function):
+    """out = a*ma + scale[c]*keep[b]*(r*mr)"""
+
+    @staticmethod
+    def forward(ctx, a, ma, r, mr, scale, keep):
+        a, ma, r, mr, keep = _c(a), _c(ma), _c(r), _c(mr), _c(keep)
+        B, T, C = a.shape
+        sc = scale.contiguous().view(-1)
+        out = torch.empty_like(a)
+        check(lib.avdf_affine_residual_fwd(_p(a), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(out), B, T, C,
+                                           _stream()), "affine_residual_fwd")
+        ctx.save_for_backward(ma, r, mr, sc, keep)
+        ctx.sshape = scale.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ma, r, mr, sc, keep = ctx.saved_tensors
+        B, T, C = r.shape
+        dout = dout.contiguous()
+        da = torch.empty_like(r) if ctx.needs_input_grad[0] else None
+        dr = torch.empty_like(r) if ctx.needs_input_grad[2] else None
+        ds = torch.empty_like(sc) if ctx.needs_input_grad[4] else None
+        ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, C), r) if ds is not None else None
+        check(lib.avdf_affine_residual_bwd(_p(dout), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(da), _p(dr), _p(ds),
+                                           _p(ws), B, T, C, 0, _stream()), "affine_residual_bwd")
+        return da, None, dr, None, None if ds is None else ds.view(ctx.sshape), None
+
+
+def affine_residual(a, ma, r, mr, scale, keep=None):
+    return AffineResidualFn.apply(a, ma, r, mr, scale, keep)
+
+
+class ResampleFn(torch.autograd.Function):
+    """mode 'up': y[b,t]=x[b,t//r]; mode 'down': y[b,t]=x[b,t*r] (F.interpolate nearest)."""
+
+    @staticmethod
+    def forward(ctx, x, r, mode):
+        x = _c(x)
+        B, Tin, C = x.shape
+        ctx.cfg = (B, Tin, C, r, mode)
+        if mode == "up":
+            y = torch.empty((B, Tin * r, C), dtype=x.dtype, device=x.device)
+            check(lib.avdf_upsample_fwd(_p(x), _p(y), B, Tin, C, r, _stream()), "upsample_fwd")
+        else:
+            y = torch.empty((B, Tin // r, C), dtype=x.dtype, device=x.device)
+            check(lib.avdf_downsample_fwd(_p(x), _p(y), B, Tin, C, r, _stream()), "downsample_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Tin, C, r, mode = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((B, Tin, C), dtype=dy.dtype, device=dy.device)
+        if mode == "up":
+            check(lib.avdf_upsample_bwd(_p(dy), _p(dx), B, Tin, C, r, _stream()), "upsample_bwd")
+        else:
+            check(lib.avdf_downsample_bwd(_p(dy), _p(dx), B, Tin, C, r, _stream()), "downsample_bwd")
+        return dx, None, None
+
+
+def upsample(x, r):
+    return ResampleFn.apply(x, r, "up")
+
+
+def downsample(x, r):
+    return ResampleFn.apply(x, r, "down")
+
+
+class AddUpsampledFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, small, r):
+        a, small = _c(a), _c(small)
+        B, T, C = a.shape
+        out = torch.empty_like(a)
+        check(lib.avdf_add_upsampled(_p(a), _p(small), _p(out), B, T, C, r, _stream()), "add_upsampled")
+        ctx.cfg = (B, T, C, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, C, r = ctx.cfg
+        dout = dout.contiguous()
+        ds = torch.empty((B, T // r, C), dtype=dout.dtype, device=dout.device)
+        check(lib.avdf_upsample_bwd(_p(dout), _p(ds), B, T // r, C, r, _stream()), "upsample_bwd")
+        return dout, ds, None
+
+
+def add_upsampled(a, small, r):
+    return AddUpsampledFn.apply(a, small, r)
+
+
+class ScaleRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _c(x), _c(s)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        check(lib.avdf_scale_rows(_p(x), _p(s), _p(y), M, C, _stream()), "scale_rows")
+        ctx.save_for_backward(s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = dy.shape[-1]
+        dx = torch.empty_like(dy)
+        check(lib.avdf_scale_rows(_p(dy), _p(s), _p(dx), dy.numel() // C, C, _stream()), "scale_rows")
+        return dx, None
+
+
+def scale_rows(x, s):
+    return ScaleRowsFn.apply(x, s)
+
+
+def transpose_last2(x):
+    """[B, R, C] -> [B, C, R] (no autograd: used at the plugin boundary only)."""
+    x = _c(x)
+    B, R, Cc = x.shape
+    y = torch.empty((B, Cc, R), dtype=x.dtype, device=x.device)
+    check(lib.avdf_transpose(_p(x), _p(y), B, R, Cc, _stream()), "transpose")
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# InstanceNorm + LeakyReLU, pooling
+# --------------------------------------------------------------------------------------------
+class InstNormLReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, slope):
+        x = _c(x)
+        B, T, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((B, C), dtype=x.dtype, device=x.device)
+        rstd = torch.empty((B, C), dtype=x.dtype, device=x.device)
+        check(lib.avdf_instnorm_lrelu_fwd(_p(x), _p(y), _p(mean), _p(rstd), B, T, C, eps, slope, _stream()),
+              "instnorm_lrelu_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        B, T, C = x.shape
+        dx = torch.empty_like(x)
+        check(lib.avdf_instnorm_lrelu_bwd(_p(dy.contiguous()), _p(x), _p(mean), _p(rstd), _p(dx), B, T, C, ctx.slope,
+                                          _stream()), "instnorm_lrelu_bwd")
+        return dx, None, None
+
+
+def instnorm_lrelu(x, eps=1e-5, slope=0.2):
+    return InstNormLReluFn.apply(x, eps, slope)
+
+
+class MaxAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, T, C = x.shape
+        y = torch.empty((B, 2 * C), dtype=x.dtype, device=x.device)
+        check(lib.avdf_maxavgpool_fwd(_p(x), _p(y), B, T, C, _stream()), "maxavgpool_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, T, C = x.shape
+        dx = torch.empty_like(x)
+        check(lib.avdf_maxavgpool_bwd(_p(dy.contiguous()), _p(x), _p(dx), B, T, C, _stream()), "maxavgpool_bwd")
+        return dx
+
+
+def maxavgpool(x):
+    return MaxAvgPoolFn.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
+# narrow-output conv
+# --------------------------------------------------------------------------------------------
+class SmallConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, mask, scale):
+        x, w, bias, mask = _c(x), _c(w), _c(bias), _c(mask)
+        B, T, Cin = x.shape
+        Cout, _, K = w.shape
+        sc = None if scale is None else scale.contiguous().view(1)
+        y = torch.empty((B, T, Cout), dtype=x.dtype, device=x.device)
+        check(lib.avdf_smallconv_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(sc), _p(y), B, T, Cin, Cout, K, _stream()),
+              "smallconv_fwd")
+        ctx.save_for_backward(x, w, mask, sc, y)
+        ctx.cfg = (B, T, Cin, Cout, K, bias is not None, None if scale is None else scale.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mask, sc, y = ctx.saved_tensors
+        B, T, Cin, Cout, K, has_bias, sshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, dtype=w.dtype, device=w.device) if has_bias else None
+        ds = torch.empty(1, dtype=w.dtype, device=w.device) if sc is not None else None
+        ws = _ws(lib.avdf_smallconv_bwd_ws(B, T, Cin, Cout, K), x)
+        check(lib.avdf_smallconv_bwd(_p(dy), _p(x), _p(w), _p(y), _p(mask), _p(sc), _p(dx), _p(dw), _p(db), _p(ds),
+                                     _p(ws), B, T, Cin, Cout, K, 0, _stream()), "smallconv_bwd")
+        return dx, dw, db, None, None if ds is None else ds.view(sshape)
+
+
+def smallconv(x, w, bias=None, mask=None, scale=None):
+    return SmallConvFn.apply(x, w, bias, mask, scale)
+
+
+# --------------------------------------------------------------------------------------------
+# K1: interpolation + concat (no autograd: inputs are frozen features)
+# --------------------------------------------------------------------------------------------
+def interp_concat(streams, out_len, out=None):
+    """streams: list of [T_s, C_s] time-major fp32 device tensors -> [out_len, sum C_s]."""
+    ctot = sum(int(s.shape[1]) for s in streams)
+    if out is None:
+        out = torch.empty((out_len, ctot), dtype=torch.float32, device=streams[0].device)
+    assert out.shape == (out_len, ctot) and out.is_contiguous()
+    off = 0
+    for s in streams:
+        s = _c(s)
+        check(lib.avdf_interp_linear(_p(s), _p(out), int(s.shape[0]), int(s.shape[1]), out_len, ctot, off, _stream()),
+              "interp_linear")
+        off += int(s.shape[1])
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+class LocLossFn(torch.autograd.Function):
+    """Returns out[5] = (cls, reg, video, final, num_pos); only out[3] carries gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, offsets, video_logits, points, pmask, gt, ngt, state, cfg, num_pos_hook):
+        logits, offsets, video_logits = _c(logits), _c(offsets), _c(video_logits)
+        B, P = logits.shape
+        G = gt.shape[1]
+        radius, center_sample, ls, lw, vw, mom = cfg
+        st = _stream()
+        ws = _ws(lib.avdf_loc_losses_ws(B, P), logits)
+        num_pos = torch.empty(1, dtype=torch.float32, device=logits.device)
+        check(lib.avdf_loc_assign(_p(points), _p(pmask), _p(gt), _p(ngt), _p(ws), _p(num_pos), B, P, G, radius,
+                                  int(center_sample), st), "loc_assign")
+        if num_pos_hook is not None:
+            num_pos_hook(num_pos)              # data parallel: all-reduce(sum) of the positive count
+        out = torch.empty(5, dtype=torch.float32, device=logits.device)
+        dlog = torch.empty_like(logits)
+        doff = torch.empty_like(offsets)
+        dvid = torch.empty_like(video_logits)
+        check(lib.avdf_loc_losses(_p(logits), _p(offsets), _p(pmask), _p(ngt), _p(video_logits), _p(ws), _p(num_pos),
+                                  _p(state), _p(out), _p(dlog), _p(doff), _p(dvid), _p(ws[B * P * 3:]), B, P,
+                                  ls, lw, vw, mom, st), "loc_losses")
+        ctx.save_for_backward(dlog, doff, dvid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dlog, doff, dvid = ctx.saved_tensors
+        g = dout[3]
+        return dlog * g, doff * g, dvid * g, None, None, None, None, None, None, None
+
+
+def loc_losses(logits, offsets, video_logits, points, pmask, gt, ngt, state, cfg, num_pos_hook=None):
+    return LocLossFn.apply(logits, offsets, video_logits, points, pmask, gt, ngt, state, cfg, num_pos_hook)
+
+
+# --------------------------------------------------------------------------------------------
+# decode + NMS
+# --------------------------------------------------------------------------------------------
+def decode_nms(points, logits, offsets, pmask, pre_nms_thresh, duration_thresh, min_score, iou_thr, voting_thr,
+               max_seg):
+    B, P = logits.shape
+    dev = logits.device
+    segs = torch.empty((B, max_seg, 2), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, max_seg), dtype=torch.float32, device=dev)
+    pidx = torch.empty((B, max_seg), dtype=torch.int32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(lib.avdf_decode_nms(_p(points), _p(_c(logits)), _p(_c(offsets)), _p(_c(pmask)), _p(segs), _p(scores),
+                              _p(pidx), _p(count), B, P, pre_nms_thresh, duration_thresh, min_score, iou_thr,
+                              voting_thr, max_seg, _stream()), "decode_nms")
+    return segs, scores, pidx, count

@@ -1,0 +1,201 @@
+/* avdf.h -- C ABI of libavdf_hip.so: the MI355X (gfx950) hot path of the
+ * audio-visual deepfake temporal-localisation system.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - activations are TIME-MAJOR [B, T, C] (the reference is channel-major [B, C, T]);
+ *   - masks are fp32 [B, T] holding 1.0 (valid) / 0.0 (padding) at the tensor's own T;
+ *   - weights keep the REFERENCE layouts: Conv1d [Cout, Cin/groups, K], Linear [out, in],
+ *     LayerNorm / AffineDropPath [1, C, 1] (read as C floats), so state-dicts are interchangeable;
+ *   - `stream` is a hipStream_t; kernels are asynchronous on it, never allocate, never sync;
+ *   - every entry point returns 0 on success or a negative AVDF_E* code; the message is
+ *     available from avdf_last_error() (thread local).
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference repo).
+ */
+#ifndef AVDF_H
+#define AVDF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVDF_OK 0
+#define AVDF_EINVAL (-22)
+#define AVDF_ELAUNCH (-5)
+
+#define AVDF_ACT_NONE 0
+#define AVDF_ACT_RELU 1
+#define AVDF_ACT_GELU 2   /* exact erf GELU (nn.GELU default) */
+
+const char* avdf_last_error(void);
+int avdf_version(void);
+
+/* ---- dense conv1d as implicit GEMM on exact-fp32 MFMA ------------------------------------
+ * Replaces MaskedConv1D.forward (libs/modeling/blocks.py:41-63) for groups==1, every 1x1
+ * nn.Conv1d / nn.Linear in the blocks (blocks.py:957-966,1291-1297,1604-1605) and the DownBlock
+ * conv (blocks.py:1498-1505).
+ *   y[b,t,n] = act( sum_{k<K} sum_{c<Cin} x[b, t*stride + k - K/2, c] * w[n,c,k] + bias[n] ) * mask[b,t]
+ * K in {1,3}, stride in {1,2}; bias/mask/ypre may be NULL; ypre (optional) receives the
+ * pre-activation (needed by the backward of act).  Cin % 4 == 0 is required.               */
+int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const float* mask,
+                    float* y, float* ypre, int B, int Tin, int Cin, int Tout, int Cout,
+                    int K, int stride, int act, void* stream);
+
+/* dx[b,t',c] = sum_k sum_n g[b,t,n] * w[n,c,k],  t*stride + k - K/2 == t',
+ * with g = dy * mask[b,t] * act'(ypre) (mask / ypre optional).  Cout % 4 == 0 required.      */
+int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,
+                         float* dx, int B, int Tin, int Cin, int Tout, int Cout,
+                         int K, int stride, int act, void* stream);
+
+/* dw[n,c,k] (+)= sum_{b,t} g[b,t,n] * x[b, t*stride + k - K/2, c];  dbias[n] (+)= sum g[b,t,n].
+ * `ws` is a caller-owned workspace of avdf_conv1d_bwd_weight_ws() floats; accumulate!=0 adds
+ * into dw/dbias instead of overwriting.  dbias may be NULL.                                  */
+int64_t avdf_conv1d_bwd_weight_ws(int B, int Tout, int Cin, int Cout, int K);
+int avdf_conv1d_bwd_weight(const float* dy, const float* x, const float* mask, const float* ypre,
+                           float* dw, float* dbias, float* ws, int B, int Tin, int Cin, int Tout,
+                           int Cout, int K, int stride, int act, int accumulate, void* stream);
+
+/* ---- channel LayerNorm (libs/modeling/blocks.py:97-112), rows = tokens -------------------
+ * y = (x-mean)/sqrt(var+eps)*gamma+beta over C, optional fused ReLU (backbones.py:439,
+ * av_fd_no_recon.py:84) and optional "+ pe[t,c]*mask[b,t]" (backbones.py:451,463; pe is the
+ * [T,C] time-major sinusoid table).  mean/rstd [M] are saved for the backward (may be NULL). */
+int avdf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int M, int C, float eps, int relu,
+                       const float* pe, const float* mask, int T, void* stream);
+int64_t avdf_layernorm_bwd_ws(int M, int C);
+int avdf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                       float* ws, int M, int C, int relu, int accumulate, void* stream);
+
+/* ---- depthwise conv k3 (+mask) -- query/key/value_conv (blocks.py:934-952) and fpn_convs
+ * (necks.py:48-51): y[b,t,c] = (sum_k x[b,t*stride+k-1,c]*w[c,0,k]) * mask[b,t]            */
+int avdf_dwconv_fwd(const float* x, const float* w, const float* mask, float* y,
+                    int B, int Tin, int Tout, int C, int stride, void* stream);
+int64_t avdf_dwconv_bwd_ws(int B, int Tout, int C);
+int avdf_dwconv_bwd(const float* dy, const float* x, const float* w, const float* mask,
+                    float* dx, float* dw, float* ws, int B, int Tin, int Tout, int C, int stride,
+                    int accumulate, void* stream);
+
+/* ---- banded (+-window/2) local attention == LocalMaskedMHCA steps 3-4
+ * (blocks.py:1181-1221): scores = (q*scale).k over the band, -inf outside the sequence
+ * (blocks.py:1006-1018), -1e4 on masked keys (blocks.py:1191-1203), softmax over the band,
+ * rows of masked queries zeroed (blocks.py:1207-1209), out = P.V.
+ * q,k,v,out: [B,T,H*hs] (head h = channels h*hs..), kvmask [B,T], probs [B,T,H,window].     */
+int avdf_local_attn_fwd(const float* q, const float* k, const float* v, const float* kvmask,
+                        float* out, float* probs, int B, int T, int H, int hs, int window,
+                        float scale, void* stream);
+int64_t avdf_local_attn_bwd_ws(int B, int T, int H, int window);
+int avdf_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
+                        const float* probs, float* dq, float* dk, float* dv, float* ws,
+                        int B, int T, int H, int hs, int window, float scale, void* stream);
+
+/* ---- global masked attention == MaskedMHCA core (blocks.py:299-309), Tq,Tk <= 256 ------- */
+int avdf_global_attn_fwd(const float* q, const float* k, const float* v, const float* kvmask,
+                         float* out, float* probs, int B, int Tq, int Tk, int H, int hs,
+                         float scale, void* stream);
+int64_t avdf_global_attn_bwd_ws(int B, int Tq, int Tk, int H);
+int avdf_global_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
+                         const float* kvmask, const float* probs, float* dq, float* dk, float* dv,
+                         float* ws, int B, int Tq, int Tk, int H, int hs, float scale, void* stream);
+
+/* ---- block glue ---------------------------------------------------------------------------
+ * maxpool: nn.MaxPool1d(3, stride 2, padding 1) skip path (blocks.py:1277-1281,1311)         */
+int avdf_maxpool3s2_fwd(const float* x, float* y, int B, int Tin, int C, void* stream);
+int avdf_maxpool3s2_bwd(const float* dy, const float* x, float* dx, int B, int Tin, int C, void* stream);
+/* out = a*ma + scale[c]*keep[b]*(r*mr): residual + AffineDropPath (blocks.py:1311-1313,
+ * 1397-1439); ma/mr/keep optional.                                                           */
+int avdf_affine_residual_fwd(const float* a, const float* ma, const float* r, const float* mr,
+                             const float* scale, const float* keep, float* out,
+                             int B, int T, int C, void* stream);
+int64_t avdf_affine_residual_bwd_ws(int B, int T, int C);
+int avdf_affine_residual_bwd(const float* dout, const float* ma, const float* r, const float* mr,
+                             const float* scale, const float* keep, float* da, float* dr,
+                             float* dscale, float* ws, int B, int T, int C, int accumulate, void* stream);
+/* nearest resampling of k/v sources (backbones.py:487,490) and FPN top-down (necks.py:78-80) */
+int avdf_upsample_fwd(const float* x, float* y, int B, int Tin, int C, int r, void* stream);
+int avdf_upsample_bwd(const float* dy, float* dx, int B, int Tin, int C, int r, void* stream);
+int avdf_downsample_fwd(const float* x, float* y, int B, int Tin, int C, int r, void* stream);
+int avdf_downsample_bwd(const float* dy, float* dx, int B, int Tin, int C, int r, void* stream);
+int avdf_add_upsampled(const float* a, const float* small, float* out, int B, int T, int C, int r, void* stream);
+/* y = x * s (per-row scalar s[M], e.g. dropout keep mask) */
+int avdf_scale_rows(const float* x, const float* s, float* y, int M, int C, void* stream);
+/* layout change at the plugin boundary: [B,C,T] <-> [B,T,C] */
+int avdf_transpose(const float* x, float* y, int B, int R, int Cc, void* stream);
+
+/* ---- InstanceNorm1d(eps, no affine, stats over all T) + LeakyReLU -- DownBlock
+ * (blocks.py:1508-1516) and DeepInterpolator.conv0 (blocks.py:1600-1603)                    */
+int avdf_instnorm_lrelu_fwd(const float* x, float* y, float* mean, float* rstd,
+                            int B, int T, int C, float eps, float slope, void* stream);
+int avdf_instnorm_lrelu_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                            float* dx, int B, int T, int C, float slope, void* stream);
+/* max + avg pooling over T -> [B, 2C] (blocks.py:1610-1614) */
+int avdf_maxavgpool_fwd(const float* x, float* y, int B, int T, int C, void* stream);
+int avdf_maxavgpool_bwd(const float* dy, const float* x, float* dx, int B, int T, int C, void* stream);
+
+/* ---- narrow-output conv (Cout <= 4): cls_head / offset_head (av_fd_no_recon.py:56-59,
+ * 139-142,85,155-156) and Linear(H->num_classes) (blocks.py:1605):
+ *   y[b,t,n] = f( (sum x*w + bias[n]) * mask[b,t] ),  f = relu(scale * .) if scale!=NULL     */
+int avdf_smallconv_fwd(const float* x, const float* w, const float* bias, const float* mask,
+                       const float* scale, float* y, int B, int T, int Cin, int Cout, int K, void* stream);
+int64_t avdf_smallconv_bwd_ws(int B, int T, int Cin, int Cout, int K);
+int avdf_smallconv_bwd(const float* dy, const float* x, const float* w, const float* y /* fwd output */,
+                       const float* mask, const float* scale, float* dx, float* dw, float* dbias,
+                       float* dscale, float* ws, int B, int T, int Cin, int Cout, int K,
+                       int accumulate, void* stream);
+
+/* ---- feature-length linear interpolation + channel concat (K1) --------------------------
+ * DeepFakeVideoAudioDataset.__getitem__ interp block (libs/datasets/deepfake_video_audio.py:
+ * 1722-1756): F.interpolate(linear, align_corners=False) of one [Tsrc, Csrc] time-major stream
+ * to Tout rows, written into the time-major [Tout, Ctot] model input at channel offset `coff`
+ * (call once per stream = the torch.cat of :1756).  Tsrc == Tout copies (the reference skips
+ * the video stream when it already has max_seq_len rows, :1725).                            */
+int avdf_interp_linear(const float* src, float* dst, int Tsrc, int Csrc, int Tout, int Ctot,
+                       int coff, void* stream);
+
+/* ---- training targets + losses (fused forward+gradient) ---------------------------------
+ * avdf_loc_assign: label_points_single_video (av_fd_no_recon.py:502-600) for every clip.
+ *   points [P,4]=(t,lo,hi,stride); pmask [B,P]; gt [B,G,2] (feature-grid units); ngt [B] int32
+ *   (0 => real clip: excluded from cls/reg like `vaild_idx`, :388-395,613).  Writes the targets
+ *   into ws (avdf_loc_losses_ws floats) and the number of positives into num_pos[0] (device).
+ *   Data-parallel callers all-reduce num_pos between the two calls (:645-648 uses the global count).
+ * avdf_loc_losses: sigmoid focal loss (losses.py:5-53) with label smoothing (:654-655), DIoU
+ *   (losses.py:57-117), normaliser EMA (:645-648), video-level focal loss (:688-692), weighting
+ *   (:702).  state[0] = loss_normalizer (in/out).  out: [0]=cls [1]=reg [2]=video [3]=final
+ *   [4]=num_pos.  dlogits [B,P] / doffsets [B,P,2] / dvideo [B] receive d(final)/d(.).        */
+int64_t avdf_loc_losses_ws(int B, int P);
+int avdf_loc_assign(const float* points, const float* pmask, const float* gt, const int32_t* ngt,
+                    float* ws, float* num_pos, int B, int P, int G, float radius, int center_sample,
+                    void* stream);
+int avdf_loc_losses(const float* logits, const float* offsets, const float* pmask, const int32_t* ngt,
+                    const float* video_logits, const float* ws_targets, const float* num_pos,
+                    float* state, float* out, float* dlogits, float* doffsets, float* dvideo,
+                    float* ws_partial, int B, int P, float label_smoothing, float loss_weight,
+                    float video_weight, float momentum, void* stream);
+
+/* ---- decode + 1-D NMS + voting, batched over clips (device) ------------------------------
+ * inference_single_video (av_fd_no_recon.py:760-825) + batched_nms/NMSop/seg_voting
+ * (libs/utils/nms.py:8-35,67-190) + nms_1d_cpu (libs/utils/csrc/nms_cpu.cpp:19-58).
+ * Ties are ordered (score desc, candidate index asc).  Outputs per clip: up to max_seg
+ * (seg[2], score, point index) + count; segments stay in feature-grid units.               */
+int avdf_decode_nms(const float* points, const float* logits, const float* offsets, const float* pmask,
+                    float* out_segs, float* out_scores, int32_t* out_pidx, int32_t* out_count,
+                    int B, int P, float pre_nms_thresh, float duration_thresh,
+                    float min_score, float iou_thr, float voting_thr, int max_seg, void* stream);
+
+/* host-side hard NMS with the semantics of nms_1d_cpu (libs/utils/csrc/nms_cpu.cpp:19-58);
+ * HOST pointers; returns kept indices (score-descending, stable).                           */
+int avdf_nms1d_host(const float* segs, const float* scores, int64_t n, float iou_thr,
+                    int64_t* keep, int64_t* n_keep);
+
+/* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
+int64_t avdf_sumsq_ws(void);
+int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);
+int avdf_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                   float bias_c1, float bias_c2, float clip_norm, float ema_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,360 @@
+"""Per-kernel parity on a real MI355X: every C-ABI op (forward and backward) against a plain
+PyTorch float64 CPU statement of the same reference op.  fp32 kernels, so the tolerance is a few
+fp32 ulps of the result scale (1e-5 relative to max|ref|, far inside the 1e-3 of the north star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(got, ref, what, rtol=RTOL):
+    got = got.detach().cpu().double()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max()) / scale
+    assert err <= rtol, f"{what}: rel err {err:.3e} > {rtol:.1e} (scale {scale:.3e})"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def mk_mask(B, T, lens):
+    return (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).double()
+
+
+def g32(t, grad=False):
+    return t.float().to(dev()).requires_grad_(grad)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from audio_visual_deepfake_detection_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, T, Cin, Cout, K, stride, bias, mask, act
+    (2, 96, 40, 32, 3, 1, True, True, 0),
+    (2, 200, 96, 520, 3, 1, False, True, 1),
+    (3, 96, 64, 36, 3, 2, True, True, 0),
+    (2, 72, 256, 256, 1, 1, True, False, 2),
+    (2, 50, 32, 128, 1, 1, False, True, 0),
+    (6, 768, 64, 256, 3, 1, False, True, 0),      # 128-row tile path
+    (6, 768, 64, 64, 3, 2, True, True, 0),
+    (6, 768, 256, 128, 1, 1, True, False, 2),
+    (1, 24, 2048, 256, 3, 2, True, True, 0),      # deep K loop, tiny T
+    (4, 1, 512, 256, 1, 1, False, False, 0),      # Linear on [B, 2H]
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d(ops, case):
+    B, T, Cin, Cout, K, s, has_bias, has_mask, act = case
+    x = rnd(B, T, Cin, seed=1)
+    w = rnd(Cout, Cin, K, seed=2, scale=1.0 / (Cin * K) ** 0.5)
+    b = rnd(Cout, seed=3) if has_bias else None
+    Tout = (T - 1) // s + 1 if K == 3 else T
+    m = mk_mask(B, Tout, [Tout - (i * 7) % max(Tout // 2, 1) for i in range(B)]) if has_mask else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    y = F.conv1d(xr.transpose(1, 2), wr, br, stride=s, padding=K // 2).transpose(1, 2)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.gelu(y)
+    if m is not None:
+        y = y * m[:, :, None]
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xg, wg = g32(x, True), g32(w, True)
+    bg = g32(b, True) if has_bias else None
+    yo = ops.conv1d(xg, wg, bg, g32(m) if has_mask else None, s, act)
+    close(yo, y, "conv fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "conv dgrad")
+    close(wg.grad, wr.grad, "conv wgrad")
+    if has_bias:
+        close(bg.grad, br.grad, "conv dbias")
+
+
+@pytest.mark.parametrize("C,relu,use_pe", [(32, False, False), (256, True, True), (1024, True, False), (516, False, False)])
+def test_layernorm(ops, C, relu, use_pe):
+    B, T = 3, 50
+    x = rnd(B, T, C, seed=5, scale=2.0) + 0.5
+    g, b = rnd(1, C, 1, seed=6) * 0.2 + 1.0, rnd(1, C, 1, seed=7) * 0.2
+    pe = rnd(T, C, seed=8) if use_pe else None
+    m = mk_mask(B, T, [50, 31, 7])
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (C,), gr.view(-1), br.view(-1), 1e-5)
+    if relu:
+        y = F.relu(y)
+    if use_pe:
+        y = y + pe[None] * m[:, :, None]
+    gy = rnd(B, T, C, seed=9)
+    y.backward(gy)
+    xg, gg, bg = g32(x, True), g32(g, True), g32(b, True)
+    yo = ops.layernorm(xg, gg, bg, 1e-5, relu, g32(pe) if use_pe else None, g32(m) if use_pe else None)
+    close(yo, y, "ln fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "ln dx")
+    close(gg.grad, gr.grad, "ln dgamma")
+    close(bg.grad, br.grad, "ln dbeta")
+
+
+@pytest.mark.parametrize("stride,C,T", [(1, 32, 96), (2, 256, 100), (1, 260, 10)])
+def test_dwconv(ops, stride, C, T):
+    B = 3
+    x, w = rnd(B, T, C, seed=1), rnd(C, 1, 3, seed=2)
+    Tout = (T - 1) // stride + 1
+    m = mk_mask(B, Tout, [Tout, Tout // 2 + 1, 1])
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv1d(xr.transpose(1, 2), wr, None, stride=stride, padding=1, groups=C).transpose(1, 2) * m[:, :, None]
+    gy = rnd(*y.shape, seed=3)
+    y.backward(gy)
+    xg, wg = g32(x, True), g32(w, True)
+    yo = ops.dwconv(xg, wg, g32(m), stride)
+    close(yo, y, "dwconv fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "dwconv dx")
+    close(wg.grad, wr.grad, "dwconv dw")
+
+
+def ref_local_attn(q, k, v, m, H, W):
+    B, T, C = q.shape
+    hs = C // H
+    w = W // 2
+    qh = q.view(B, T, H, hs).permute(0, 2, 1, 3) / hs ** 0.5
+    kh = k.view(B, T, H, hs).permute(0, 2, 1, 3)
+    vh = v.view(B, T, H, hs).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2)
+    idx = torch.arange(T)
+    band = (idx[None, :] - idx[:, None]).abs() <= w
+    s = s + ((1 - m) * -1e4)[:, None, None, :]
+    s = s.masked_fill(~band[None, None], float("-inf"))
+    p = torch.softmax(s, -1) * m[:, None, :, None]
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
+
+
+@pytest.mark.parametrize("H,hs,W,T", [(4, 8, 7, 48), (4, 64, 7, 96), (2, 16, 3, 24), (4, 32, 9, 64)])
+def test_local_attention(ops, H, hs, W, T):
+    B, C = 2, H * hs
+    q, k, v = rnd(B, T, C, seed=1), rnd(B, T, C, seed=2), rnd(B, T, C, seed=3)
+    m = mk_mask(B, T, [T, T // 2 + 3])
+    qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    y = ref_local_attn(qr, kr, vr, m, H, W)
+    gy = rnd(B, T, C, seed=4)
+    y.backward(gy)
+    qg, kg, vg = g32(q, True), g32(k, True), g32(v, True)
+    yo = ops.local_attention(qg, kg, vg, g32(m), H, W)
+    close(yo, y, "local attn fwd")
+    yo.backward(g32(gy))
+    close(qg.grad, qr.grad, "local attn dq")
+    close(kg.grad, kr.grad, "local attn dk")
+    close(vg.grad, vr.grad, "local attn dv")
+
+
+@pytest.mark.parametrize("H,hs,Tq,Tk", [(4, 64, 24, 24), (2, 16, 6, 6), (4, 8, 70, 130)])
+def test_global_attention(ops, H, hs, Tq, Tk):
+    B, C = 2, H * hs
+    q, k, v = rnd(B, Tq, C, seed=1), rnd(B, Tk, C, seed=2), rnd(B, Tk, C, seed=3)
+    m = mk_mask(B, Tk, [Tk, Tk // 2 + 1])
+    qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    qh = qr.view(B, Tq, H, hs).permute(0, 2, 1, 3) / hs ** 0.5
+    kh = kr.view(B, Tk, H, hs).permute(0, 2, 1, 3)
+    vh = vr.view(B, Tk, H, hs).permute(0, 2, 1, 3)
+    att = (qh @ kh.transpose(-1, -2)).masked_fill(m[:, None, None, :] == 0, float("-inf"))
+    y = (torch.softmax(att, -1) @ (vh * m[:, None, :, None])).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    gy = rnd(B, Tq, C, seed=4)
+    y.backward(gy)
+    qg, kg, vg = g32(q, True), g32(k, True), g32(v, True)
+    yo = ops.global_attention(qg, kg, vg, g32(m), H)
+    close(yo, y, "global attn fwd")
+    yo.backward(g32(gy))
+    close(qg.grad, qr.grad, "global attn dq")
+    close(kg.grad, kr.grad, "global attn dk")
+    close(vg.grad, vr.grad, "global attn dv")
+
+
+def test_maxpool_and_residual(ops):
+    B, T, C = 3, 96, 64
+    x = rnd(B, T, C, seed=1)
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool1d(xr.transpose(1, 2), 3, 2, 1).transpose(1, 2)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xg = g32(x, True)
+    yo = ops.maxpool3s2(xg)
+    close(yo, y, "maxpool fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "maxpool bwd")
+
+    a, r = rnd(B, T, C, seed=3), rnd(B, T, C, seed=4)
+    sc = rnd(1, C, 1, seed=5)
+    keep = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9], dtype=torch.float64)
+    ma, mr = mk_mask(B, T, [96, 40, 9]), mk_mask(B, T, [90, 41, 96])
+    ar, rr, sr = a.clone().requires_grad_(True), r.clone().requires_grad_(True), sc.clone().requires_grad_(True)
+    out = ar * ma[:, :, None] + sr.view(1, 1, C) * keep[:, None, None] * (rr * mr[:, :, None])
+    go = rnd(B, T, C, seed=6)
+    out.backward(go)
+    ag, rg, sg = g32(a, True), g32(r, True), g32(sc, True)
+    oo = ops.affine_residual(ag, g32(ma), rg, g32(mr), sg, g32(keep))
+    close(oo, out, "affine_residual fwd")
+    oo.backward(g32(go))
+    close(ag.grad, ar.grad, "affine_residual da")
+    close(rg.grad, rr.grad, "affine_residual dr")
+    close(sg.grad, sr.grad, "affine_residual dscale")
+    # optional operands absent
+    o2 = ops.affine_residual(g32(a), None, g32(r), None, g32(sc), None)
+    close(o2, a + sc.view(1, 1, C) * r, "affine_residual (no masks)")
+
+
+def test_resample_transpose(ops):
+    B, T, C = 2, 24, 32
+    x = rnd(B, T, C, seed=1)
+    for r in (2, 4, 32):
+        xr = x.clone().requires_grad_(True)
+        y = xr.repeat_interleave(r, dim=1)
+        gy = rnd(*y.shape, seed=2)
+        y.backward(gy)
+        xg = g32(x, True)
+        yo = ops.upsample(xg, r)
+        close(yo, y, "upsample fwd")
+        yo.backward(g32(gy))
+        close(xg.grad, xr.grad, "upsample bwd")
+    big = rnd(B, 96, C, seed=3)
+    for r in (2, 8):
+        br = big.clone().requires_grad_(True)
+        y = br[:, ::r]
+        gy = rnd(*y.shape, seed=4)
+        y.backward(gy)
+        bg = g32(big, True)
+        yo = ops.downsample(bg, r)
+        close(yo, y, "downsample fwd")
+        yo.backward(g32(gy))
+        close(bg.grad, br.grad, "downsample bwd")
+    a, s = rnd(B, 48, C, seed=5), rnd(B, 24, C, seed=6)
+    ar, sr = a.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    out = ar + sr.repeat_interleave(2, dim=1)
+    go = rnd(B, 48, C, seed=7)
+    out.backward(go)
+    ag, sg = g32(a, True), g32(s, True)
+    oo = ops.add_upsampled(ag, sg, 2)
+    close(oo, out, "add_upsampled fwd")
+    oo.backward(g32(go))
+    close(ag.grad, ar.grad, "add_upsampled da")
+    close(sg.grad, sr.grad, "add_upsampled dsmall")
+    z = rnd(3, 45, 70, seed=8)
+    close(ops.transpose_last2(g32(z)), z.transpose(1, 2), "transpose", rtol=0.0)
+    rows = rnd(12, seed=9)
+    close(ops.scale_rows(g32(z[0, :12]), g32(rows)), z[0, :12] * rows[:, None], "scale_rows")
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 384, 256), (3, 24, 100), (2, 48, 2048)])
+def test_instnorm_pool(ops, B, T, C):
+    x = rnd(B, T, C, seed=1, scale=1.5) + 0.3
+    xr = x.clone().requires_grad_(True)
+    y = F.leaky_relu(F.instance_norm(xr.transpose(1, 2), eps=1e-5), 0.2).transpose(1, 2)
+    gy = rnd(B, T, C, seed=2)
+    y.backward(gy)
+    xg = g32(x, True)
+    yo = ops.instnorm_lrelu(xg, 1e-5, 0.2)
+    close(yo, y, "instnorm fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "instnorm bwd", rtol=1e-4)
+    xr2 = x.clone().requires_grad_(True)
+    p = torch.cat((xr2.max(dim=1).values, xr2.mean(dim=1)), dim=1)
+    gp = rnd(B, 2 * C, seed=3)
+    p.backward(gp)
+    xg2 = g32(x, True)
+    po = ops.maxavgpool(xg2)
+    close(po, p, "maxavgpool fwd")
+    po.backward(g32(gp))
+    close(xg2.grad, xr2.grad, "maxavgpool bwd")
+
+
+@pytest.mark.parametrize("N,K,Cin,T,use_scale", [(1, 3, 256, 96, False), (2, 3, 256, 50, True), (1, 1, 32, 1, False),
+                                                 (2, 3, 520, 24, True)])
+def test_smallconv(ops, N, K, Cin, T, use_scale):
+    B = 3
+    x = rnd(B, T, Cin, seed=1)
+    w = rnd(N, Cin, K, seed=2, scale=1.0 / (Cin * K) ** 0.5)
+    b = rnd(N, seed=3)
+    m = mk_mask(B, T, [T, max(T // 2, 1), 1])
+    sc = torch.tensor(1.3, dtype=torch.float64)
+    xr, wr, br, sr = [t.clone().requires_grad_(True) for t in (x, w, b, sc)]
+    y = F.conv1d(xr.transpose(1, 2), wr, br, padding=K // 2).transpose(1, 2) * m[:, :, None]
+    if use_scale:
+        y = F.relu(y * sr)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xg, wg, bg, sg = g32(x, True), g32(w, True), g32(b, True), g32(sc, True)
+    yo = ops.smallconv(xg, wg, bg, g32(m), sg if use_scale else None)
+    close(yo, y, "smallconv fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "smallconv dx")
+    close(wg.grad, wr.grad, "smallconv dw")
+    close(bg.grad, br.grad, "smallconv dbias")
+    if use_scale:
+        close(sg.grad, sr.grad, "smallconv dscale")
+
+
+def test_interp_concat_matches_reference_vectors(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "interp.npz"))
+    ka = ops.interp_concat([torch.tensor(np.tile(g["known_in"][:, None], (1, 4))).to(dev())], 8)
+    assert torch.equal(ka[:, 0].cpu(), torch.from_numpy(g["known_out"]))      # deepfake_video_audio.py:1726
+    for i in range(int(g["n_cases"])):
+        # channel counts in the fixture (6, 10, 4) are not multiples of 4: pad each stream to 12 channels
+        streams, refs = [], []
+        for key in ("v", "a", "e"):
+            a = g[f"{key}{i}"]
+            pad = np.zeros((a.shape[0], 12), np.float32)
+            pad[:, :a.shape[1]] = a
+            streams.append(torch.from_numpy(pad).to(dev()))
+        out = ops.interp_concat(streams, 768).cpu().numpy()                     # [768, 36] time-major
+        ref = g[f"out{i}"]                                                      # [20, 768] channel-major
+        got = np.concatenate([out[:, 0:6], out[:, 12:22], out[:, 24:28]], axis=1).T
+        assert np.array_equal(got, ref), f"interp case {i}: max diff {np.abs(got - ref).max():.3e}"
+
+
+def test_adamw_ema_kernel(ops):
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    n = 10007
+    p0, g0 = rnd(n, seed=1).float(), rnd(n, seed=2).float()
+    pr = p0.clone().double().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ema_ref = p0.clone().double()
+    p, m, v, ema = p0.to(dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev()), p0.to(dev())
+    nsq = torch.zeros(1, device=dev())
+    ws = torch.empty(int(lib.avdf_sumsq_ws()), device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(1, 4):
+        g = (g0 * step).double()
+        gn = g.norm()
+        clip = min(1.0 / (float(gn) + 1e-6), 1.0)
+        pr.grad = g * clip
+        opt.step()
+        ema_ref = ema_ref * 0.999 + 0.001 * pr.detach()
+        gd = (g0 * step).to(dev())
+        nsq.zero_()
+        check(lib.avdf_sumsq(gd.data_ptr(), nsq.data_ptr(), ws.data_ptr(), n, st), "sumsq")
+        check(lib.avdf_adamw_ema(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(),
+                                 nsq.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1 - 0.9 ** step, 1 - 0.999 ** step,
+                                 1.0, 0.999, st), "adamw")
+        close(nsq.sqrt(), gn.view(1), "grad norm")
+    close(p, pr.detach(), "adamw params", rtol=1e-5)
+    close(ema, ema_ref, "ema", rtol=1e-5)
