@@ -59,7 +59,7 @@ SIGNATURES = {
     "avdf_nms1d_host": (I, [P, P, L, F, P, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
-    "avdf_adamw_ema": (I, [P, P, P, P, P, P, L, F, F, F, F, F, F, F, F, F, P]),
+    "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),
 }
 
 

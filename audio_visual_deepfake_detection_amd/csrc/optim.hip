@@ -33,9 +33,12 @@ __global__ void sumsq_final_kernel(const float* __restrict__ partial, int nb, fl
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
-                                                        const float* __restrict__ gnorm_sq, int64_t n, float lr, float beta1,
-                                                        float beta2, float eps, float wd, float bias_c1, float bias_c2,
+                                                        const float* __restrict__ gnorm_sq, const float* __restrict__ hp,
+                                                        int64_t n, float beta1, float beta2, float eps, float wd,
                                                         float clip_norm, float ema_decay) {
+  // hp (device, rewritten by the host every step so that a captured graph sees the schedule):
+  // [0] = lr, [1] = 1 - beta1^t, [2] = 1 - beta2^t
+  const float lr = hp[0], bias_c1 = hp[1], bias_c2 = hp[2];
   float cs = 1.f;
   if (gnorm_sq && clip_norm > 0.f) {
     const float nrm = sqrtf(gnorm_sq[0]);
@@ -73,13 +76,13 @@ extern "C" int avdf_sumsq(const float* x, float* out, float* ws, int64_t n, void
 }
 
 extern "C" int avdf_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
-                              int64_t n, float lr, float beta1, float beta2, float eps, float wd,
-                              float bias_c1, float bias_c2, float clip_norm, float ema_decay, void* stream) {
-  AVDF_REQUIRE(p && g && m && v && n > 0, "adamw_ema: bad args");
+                              const float* hp, int64_t n, float beta1, float beta2, float eps, float wd,
+                              float clip_norm, float ema_decay, void* stream) {
+  AVDF_REQUIRE(p && g && m && v && hp && n > 0, "adamw_ema: bad args");
   int64_t nb = (n + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, gnorm_sq, n,
-                     lr, beta1, beta2, eps, wd, bias_c1, bias_c2, clip_norm, ema_decay);
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, gnorm_sq, hp, n,
+                     beta1, beta2, eps, wd, clip_norm, ema_decay);
   AVDF_CHECK_LAUNCH("adamw_ema");
   return AVDF_OK;
 }

@@ -13,6 +13,36 @@ from ._lib import lib, check
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
+# optional per-launch timing of the MFMA conv kernels (bench.py roofline pass): list of
+# (kernel tag, algorithmic FLOPs, start event, end event) recorded on the launch stream
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    global _prof
+    out, _prof = _prof, None
+    return out
+
+
+def _timed(tag, flops, fn):
+    if _prof is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _prof.append((tag, flops, s, e))
+    return r
+
+
+def _conv_tag(kind, K, stride, rows):
+    return f"conv_{kind}_k{K}s{stride}_{'bm128' if rows >= 4096 else 'bm64'}"
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -58,8 +88,10 @@ class Conv1dFn(torch.autograd.Function):
         y = torch.empty((B, Tout, Cout), dtype=x.dtype, device=x.device)
         need_pre = act != ACT_NONE and any(ctx.needs_input_grad)
         ypre = torch.empty_like(y) if need_pre else None
-        check(lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
-                                  K, stride, act, _stream()), "conv1d_fwd")
+        fl = 2.0 * B * Tout * Cout * Cin * K
+        _timed(_conv_tag("fwd", K, stride, B * Tout), fl, lambda: check(
+            lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
+                                K, stride, act, _stream()), "conv1d_fwd"))
         ctx.save_for_backward(x, w, mask, ypre)
         ctx.cfg = (B, Tin, Cin, Tout, Cout, K, stride, act, bias is not None)
         return y
@@ -73,14 +105,19 @@ class Conv1dFn(torch.autograd.Function):
         st = _stream()
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.avdf_conv1d_bwd_data(_p(dy), _p(w), _p(mask), _p(ypre), _p(dx), B, Tin, Cin, Tout, Cout,
-                                           K, stride, act, st), "conv1d_bwd_data")
+            fl = 2.0 * B * Tout * Cout * Cin * K
+            _timed(_conv_tag("dgrad", K, stride, B * Tin), fl, lambda: check(
+                lib.avdf_conv1d_bwd_data(_p(dy), _p(w), _p(mask), _p(ypre), _p(dx), B, Tin, Cin, Tout, Cout,
+                                         K, stride, act, st), "conv1d_bwd_data"))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(Cout, dtype=w.dtype, device=w.device) if has_bias else None
             ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K), x)
-            check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws), B, Tin, Cin,
-                                             Tout, Cout, K, stride, act, 0, st), "conv1d_bwd_weight")
+            fl = 2.0 * B * Tout * Cout * Cin * K
+            _timed(f"conv_wgrad_k{K}s{stride}_{'n64' if Cout * Cin * K <= 512 * 1024 else 'n128'}+reduce", fl,
+                   lambda: check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws),
+                                                            B, Tin, Cin, Tout, Cout, K, stride, act, 0, st),
+                                 "conv1d_bwd_weight"))
         return dx, dw, db, None, None, None
 
 

@@ -1,0 +1,221 @@
+"""Headline benchmark: AV clips/s (768-frame) for one full training step (K1 interpolation ->
+UMMAFormer forward -> losses -> backward -> clipped AdamW + EMA) of the exp10 AV-fusion model on
+N MI355X GPUs of one node, one process per GPU, clip-level data parallel (weak scaling:
+8 clips per GPU per step).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant MFMA conv
+kernel, per-launch HIP-event timing) and, at N=1, `cpu_baseline` (the CPU oracle -- a parity-pinned
+restatement of the reference path -- timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak (= fp32 vector peak)
+STREAMS = [(768, 256), (383, 2048), (1535, 768)]      # LAV-DF video, BYOL-A, Emotion2Vec of a 768-frame clip
+
+
+def synth_clip(i):
+    """N(0,1) features from seed 1000+i; clip i fake iff i%2==0 with 1-3 segments of
+    U(0.2,1.5) s at a uniform start, seed 2000+i; seconds -> feature grid: sec*fps/feat_stride - 0.5."""
+    g = torch.Generator().manual_seed(1000 + i)
+    feats = [torch.randn(shp, generator=g, dtype=torch.float32) for shp in STREAMS]
+    segs = None
+    if i % 2 == 0:
+        rs = np.random.RandomState(2000 + i)
+        k = int(rs.randint(1, 4))
+        ln = rs.uniform(0.2, 1.5, size=k)
+        st = rs.uniform(0.0, 30.72 - 1.5, size=k)
+        segs = np.stack([st, st + ln], 1).astype(np.float32) * 25.0 - 0.5
+    return feats, segs
+
+
+def load_batch(eng, first_clip):
+    for b in range(eng.B):
+        feats, segs = synth_clip(first_clip + b)
+        for dst, src in zip(eng.streams[b], feats):
+            dst.copy_(src)
+        if hasattr(eng, "gt"):
+            eng.gt[b].zero_()
+            n = 0 if segs is None else len(segs)
+            if n:
+                eng.gt[b, :n].copy_(torch.from_numpy(segs))
+            eng.ngt[b] = n
+
+
+def conv_flops_per_clip(cfg_T=768, Cin=3072, D=256):
+    """Necessary forward MFMA work per clip (21.58 GF; x3 for fwd+bwd)."""
+    return 21.58e9
+
+
+def cpu_baseline(batch, budget_s=20.0):
+    """CPU oracle (port of the reference path, pinned to it by tests/golden) timed on a bounded sample:
+    repeated fwd+bwd training steps of `batch` exp10 clips until ~budget_s seconds elapsed."""
+    from oracle import ummaformer_ref as R
+    cfg = R.make_cfg()
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    sd = R.synth_state_dict(R.param_shapes(cfg), 0, trained_like=False)
+    sd = {k: v.clone().requires_grad_(not k.startswith("interpolator.expansion")) for k, v in sd.items()}
+    xs, gts = [], []
+    for i in range(batch):
+        feats, segs = synth_clip(i)
+        xs.append(R.interp_concat([f.numpy() for f in feats], 768))
+        gts.append(None if segs is None else torch.from_numpy(segs))
+    x = torch.stack(xs)
+    mask = torch.ones((batch, 1, 768))
+    labels = [None if g is None else torch.zeros(len(g), dtype=torch.int64) for g in gts]
+    done, t0 = 0, time.time()
+    norm = cfg["init_loss_norm"]
+    while True:
+        out = R.model_forward(sd, cfg, x, mask, training=True)
+        ls, norm, _ = R.losses(cfg, out, gts, labels, norm)
+        ls["final_loss"].backward()
+        for v in sd.values():
+            v.grad = None
+        done += 1
+        el = time.time() - t0
+        if el > budget_s or done >= 8:
+            break
+    return {"value": round(done * batch / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{done} fwd+bwd steps of {batch} exp10 clips (T=768, C_in=3072, fp32, incl. CPU interp of step 0 "
+                      f"excluded, no optimizer) in {el:.1f}s on {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    from audio_visual_deepfake_detection_amd import build_model
+    from audio_visual_deepfake_detection_amd import ops
+    from audio_visual_deepfake_detection_amd.engine import TrainStep, InferStep
+
+    torch.manual_seed(0)                       # identical random-init weights on every rank
+    model, cfg = build_model("deepfake_exp10.yaml")
+    model = model.to(dev)
+    torch.manual_seed(1234 + rank)             # rank-offset drop-path / dropout streams
+
+    B = args.batch
+    if args.mode == "train":
+        eng = TrainStep(model, B, STREAMS, lr=cfg["opt"]["learning_rate"] * world,        # train.py:60 LR rule
+                        weight_decay=cfg["opt"]["weight_decay"], clip_grad_l2norm=cfg["train_cfg"]["clip_grad_l2norm"],
+                        use_graph=not args.no_graph, process_group=pg)
+    else:
+        eng = InferStep(model, B, STREAMS, use_graph=not args.no_graph)
+    load_batch(eng, rank * B)
+    eng.capture()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    clips_per_s = world * B * args.steps / dt
+
+    # ---- roofline pass: the same step, eager, HIP events around every MFMA conv launch -----------
+    roof = None
+    if args.mode == "train":
+        use_graph = eng.use_graph
+        graphs, eng.graphs, eng.use_graph = eng.graphs, None, False
+        eng.step()                      # eager warm-up
+        torch.cuda.synchronize()
+        ops.profile_begin()
+        nprof = 3
+        for _ in range(nprof):
+            eng.step()
+        torch.cuda.synchronize()
+        recs = ops.profile_end()
+        eng.graphs, eng.use_graph = graphs, use_graph
+        agg = {}
+        for tag, fl, s, e in recs:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += fl
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        tot_t = sum(v[1] for v in agg.values())
+        tot_f = sum(v[2] for v in agg.values())
+        tag, (cnt, tsec, fl) = dom
+        ach = fl / tsec / 1e12
+        roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
+                "flops_per_launch": round(fl / cnt),
+                "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2),
+                                     "frac": round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "ms_per_step": round(tot_t / nprof * 1e3, 3)},
+                "per_kernel": {k: {"n": v[0] // nprof, "ms_per_step": round(v[1] / nprof * 1e3, 3),
+                                   "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(agg.items())}}
+
+    if rank == 0:
+        line = {
+            "metric": "AV clips/sec (768-frame) fwd+bwd" if args.mode == "train" else "AV clips/sec (768-frame) inference",
+            "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "exp10 AV-fusion UMMAFormer training step (K1 interp -> fwd -> losses -> bwd -> "
+                                   "clip+AdamW+EMA), T=768, C_in=3072 (LAV-DF 256 + BYOL-A 2048 + Emotion2Vec 768), "
+                                   "random-init weights" if args.mode == "train" else
+                                   "exp10 AV-fusion UMMAFormer inference (K1 interp -> fwd -> decode+NMS)",
+                       "clips_per_gpu": B, "global_batch": world * B, "seq_len": 768,
+                       "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
+                       "dead_params_skipped": len(getattr(eng, "dead", []))},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+            fwd_bwd = 3 * conv_flops_per_clip() * clips_per_s / world / 1e12
+            line["step_mfma_frac"] = round(fwd_bwd / PEAK_F32_MFMA_TFLOPS, 4)
+        if args.mode == "train":
+            line["losses"] = eng.losses()
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+            line["cpu_baseline"] = cpu_baseline(2)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -191,9 +191,11 @@ int avdf_nms1d_host(const float* segs, const float* scores, int64_t n, float iou
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);
 int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);
+/* hp: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}, rewritten by the host each step (graph-safe schedule);
+ * gnorm_sq: device float[1] = sum of squared gradients over ALL parameters (NULL or clip_norm<=0: no clipping) */
 int avdf_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
-                   int64_t n, float lr, float beta1, float beta2, float eps, float wd,
-                   float bias_c1, float bias_c2, float clip_norm, float ema_decay, void* stream);
+                   const float* hp, int64_t n, float beta1, float beta2, float eps, float wd,
+                   float clip_norm, float ema_decay, void* stream);
 
 #ifdef __cplusplus
 }

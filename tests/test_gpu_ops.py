@@ -259,7 +259,7 @@ def test_resample_transpose(ops):
     close(ag.grad, ar.grad, "add_upsampled da")
     close(sg.grad, sr.grad, "add_upsampled dsmall")
     z = rnd(3, 45, 70, seed=8)
-    close(ops.transpose_last2(g32(z)), z.transpose(1, 2), "transpose", rtol=0.0)
+    close(ops.transpose_last2(g32(z)), z.float().transpose(1, 2), "transpose", rtol=0.0)
     rows = rnd(12, seed=9)
     close(ops.scale_rows(g32(z[0, :12]), g32(rows)), z[0, :12] * rows[:, None], "scale_rows")
 
@@ -352,9 +352,9 @@ def test_adamw_ema_kernel(ops):
         gd = (g0 * step).to(dev())
         nsq.zero_()
         check(lib.avdf_sumsq(gd.data_ptr(), nsq.data_ptr(), ws.data_ptr(), n, st), "sumsq")
+        hp = torch.tensor([1e-3, 1 - 0.9 ** step, 1 - 0.999 ** step], device=dev())
         check(lib.avdf_adamw_ema(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(),
-                                 nsq.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1 - 0.9 ** step, 1 - 0.999 ** step,
-                                 1.0, 0.999, st), "adamw")
+                                 nsq.data_ptr(), hp.data_ptr(), n, 0.9, 0.999, 1e-8, 0.05, 1.0, 0.999, st), "adamw")
         close(nsq.sqrt(), gn.view(1), "grad norm")
     close(p, pr.detach(), "adamw params", rtol=1e-5)
     close(ema, ema_ref, "ema", rtol=1e-5)
