@@ -61,3 +61,6 @@ __device__ __forceinline__ float act_grad_f(float pre, int act) {
 
 // sum `nslab` partial vectors of length n: out[i] (+)= sum_s ws[s*n + i]
 int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int accumulate, hipStream_t st);
+// same, columns [split, n) are written to out2[0 .. n-split)
+int avdf_reduce_slabs2(const float* ws, float* out, float* out2, int nslab, int64_t n, int64_t split,
+                       int accumulate, hipStream_t st);

@@ -461,18 +461,67 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   }
 }
 
+// out[i] (+)= sum_s ws[s*n + i].  Columns >= split go to out2[i - split] (two results from one
+// slab set, e.g. LayerNorm dgamma|dbeta).  Small n: 64 columns x 16 slab phases per 1024-thread block
+// (many independent loads in flight instead of one serial chain per column).
+__global__ __launch_bounds__(1024) void reduce_slabs_small_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                 float* __restrict__ out2, int nslab, int n, int split,
+                                                                 int accumulate) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (col < n) {
+#pragma unroll 4
+    for (int k = ph; k < nslab; k += 16) s += ws[(size_t)k * n + col];
+  }
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && col < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    float* o = col < split ? out + col : out2 + (col - split);
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+// large n (multiple of 4): one float4 column group per thread, streaming over the slabs
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int nslab, int64_t n, int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += ws[(size_t)k * n + i];
-    out[i] = accumulate ? out[i] + s : s;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = 0; k < nslab; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)k * n + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out + i * 4);
+    if (accumulate) { const float4 c = *o; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+    *o = s;
   }
 }
 
 constexpr int kColsumBlocks = 128;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Output-tile choice for the forward / dgrad GEMMs.  The problems are small for a 256-CU chip
+// (e.g. 6144 x 256 outputs = 1536 MFMA tiles for 1024 SIMDs), so the largest tile that still yields
+// >= 2 workgroups per CU wins; otherwise the shape with the most workgroups.
+// 0: 128x128  1: 64x128  2: 64x64  3: 32x128
+inline int pick_tile(int B, int T, int N) {
+  const int bm[4] = {128, 64, 64, 32}, bn[4] = {128, 128, 64, 128};
+  int best = 0;
+  long best_blocks = -1;
+  for (int c = 0; c < 4; ++c) {
+    const long blocks = (long)B * cdiv(T, bm[c]) * cdiv(N, bn[c]);
+    if (blocks >= 512) return c;
+    if (blocks > best_blocks) { best_blocks = blocks; best = c; }
+  }
+  return best;
+}
 
 struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles; bool small; };
 inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
@@ -494,13 +543,24 @@ inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
 
 }  // namespace
 
-int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int accumulate, hipStream_t st) {
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, out, nslab, n, accumulate);
+int avdf_reduce_slabs2(const float* ws, float* out, float* out2, int nslab, int64_t n, int64_t split,
+                       int accumulate, hipStream_t st) {
+  const bool vec_ok = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && out2 == nullptr;
+  if (n >= 32768 && vec_ok) {
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, out, nslab, n, accumulate);
+  } else {
+    hipLaunchKernelGGL(reduce_slabs_small_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, ws, out,
+                       out2 ? out2 : out, nslab, (int)n, (int)(out2 ? split : n), accumulate);
+  }
   AVDF_CHECK_LAUNCH("reduce_slabs");
   return AVDF_OK;
+}
+
+int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int accumulate, hipStream_t st) {
+  return avdf_reduce_slabs2(ws, out, nullptr, nslab, n, n, accumulate, st);
 }
 
 extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const float* mask,
@@ -514,18 +574,26 @@ extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd: Tout=%d inconsistent with Tin=%d K=%d s=%d", Tout, Tin, K, stride);
   AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd: x/w must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_FWD(KS_, S_, WM_, WN_, MI_, NI_)                                                     \
+  const int cfg = pick_tile(B, Tout, Cout);
+#define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_)                                                 \
   do {                                                                                              \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                       \
     const int tilesT = cdiv(Tout, BM_);                                                             \
     dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                         \
-    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, 16>), grid, dim3(256), 0, st,  \
+    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_>), grid, dim3(256), 0, st, \
                        x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT);            \
   } while (0)
-  const bool big = (int64_t)B * Tout >= 4096;      // enough rows to fill the chip with 128-row tiles
-  if (K == 3 && stride == 1) { if (big) LAUNCH_FWD(3, 1, 2, 2, 2, 2); else LAUNCH_FWD(3, 1, 2, 2, 1, 2); }
-  else if (K == 3 && stride == 2) { if (big) LAUNCH_FWD(3, 2, 2, 2, 2, 2); else LAUNCH_FWD(3, 2, 2, 2, 1, 2); }
-  else { if (big) LAUNCH_FWD(1, 1, 2, 2, 2, 2); else LAUNCH_FWD(1, 1, 2, 2, 1, 2); }
+#define LAUNCH_FWD_CFG(KS_, S_, KC_)                                \
+  switch (cfg) {                                                    \
+    case 0: LAUNCH_FWD(KS_, S_, KC_, 2, 2, 2, 2); break;            \
+    case 1: LAUNCH_FWD(KS_, S_, KC_, 2, 2, 1, 2); break;            \
+    case 2: LAUNCH_FWD(KS_, S_, KC_, 2, 2, 1, 1); break;            \
+    default: LAUNCH_FWD(KS_, S_, KC_, 1, 4, 1, 1); break;           \
+  }
+  if (K == 3 && stride == 1) { LAUNCH_FWD_CFG(3, 1, 16) }
+  else if (K == 3 && stride == 2) { LAUNCH_FWD_CFG(3, 2, 16) }
+  else { LAUNCH_FWD_CFG(1, 1, 32) }
+#undef LAUNCH_FWD_CFG
 #undef LAUNCH_FWD
   AVDF_CHECK_LAUNCH("conv1d_fwd");
   return AVDF_OK;
@@ -541,18 +609,26 @@ extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_data: Tout inconsistent");
   AVDF_REQUIRE(aligned16(dy) && aligned16(w) && (!ypre || aligned16(ypre)), "conv1d_bwd_data: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_DG(KS_, S_, WM_, WN_, MI_, NI_)                                                       \
+  const int cfg = pick_tile(B, Tin, Cin);
+#define LAUNCH_DG(KS_, S_, KC_, WM_, WN_, MI_, NI_)                                                   \
   do {                                                                                               \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                        \
     const int tilesT = cdiv(Tin, BM_);                                                               \
     dim3 grid(B * tilesT, cdiv(Cin, BN_));                                                           \
-    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, 16>), grid, dim3(256), 0, st, \
+    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_>), grid, dim3(256), 0, st, \
                        dy, w, mask, ypre, dx, B, Tin, Cin, Tout, Cout, act, tilesT);                 \
   } while (0)
-  const bool big = (int64_t)B * Tin >= 4096;
-  if (K == 3 && stride == 1) { if (big) LAUNCH_DG(3, 1, 2, 2, 2, 2); else LAUNCH_DG(3, 1, 2, 2, 1, 2); }
-  else if (K == 3 && stride == 2) { if (big) LAUNCH_DG(3, 2, 2, 2, 2, 2); else LAUNCH_DG(3, 2, 2, 2, 1, 2); }
-  else { if (big) LAUNCH_DG(1, 1, 2, 2, 2, 2); else LAUNCH_DG(1, 1, 2, 2, 1, 2); }
+#define LAUNCH_DG_CFG(KS_, S_, KC_)                                 \
+  switch (cfg) {                                                    \
+    case 0: LAUNCH_DG(KS_, S_, KC_, 2, 2, 2, 2); break;             \
+    case 1: LAUNCH_DG(KS_, S_, KC_, 2, 2, 1, 2); break;             \
+    case 2: LAUNCH_DG(KS_, S_, KC_, 2, 2, 1, 1); break;             \
+    default: LAUNCH_DG(KS_, S_, KC_, 1, 4, 1, 1); break;            \
+  }
+  if (K == 3 && stride == 1) { LAUNCH_DG_CFG(3, 1, 16) }
+  else if (K == 3 && stride == 2) { LAUNCH_DG_CFG(3, 2, 16) }
+  else { LAUNCH_DG_CFG(1, 1, 32) }
+#undef LAUNCH_DG_CFG
 #undef LAUNCH_DG
   AVDF_CHECK_LAUNCH("conv1d_bwd_data");
   return AVDF_OK;

@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int kLnMaxV = 8;            // float4 per lane -> C <= 2048
-constexpr int kLnBwdBlocks = 256;
+constexpr int kLnBwdBlocks = 128;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   }
 }
 
-// ws layout: [2][gridDim.x][C]  (dgamma partials, then dbeta partials)
+// ws layout: [gridDim.x][2*C]  (per block: dgamma partials, then dbeta partials)
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     float s = 0.f;
 #pragma unroll
     for (int w_ = 0; w_ < 4; ++w_) s += red[(size_t)(w_ * 2 + which) * C + c];
-    ws[((size_t)which * gridDim.x + blockIdx.x) * C + c] = s;
+    ws[(size_t)blockIdx.x * 2 * C + i] = s;
   }
 }
 
@@ -266,8 +266,11 @@ extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* 
   if (C <= 256) LN_BWD(1); else if (C <= 512) LN_BWD(2); else if (C <= 1024) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
   AVDF_CHECK_LAUNCH("layernorm_bwd");
-  if (dgamma) { int rc = avdf_reduce_slabs(ws, dgamma, G, C, accumulate, st); if (rc) return rc; }
-  if (dbeta) { int rc = avdf_reduce_slabs(ws + (size_t)G * C, dbeta, G, C, accumulate, st); if (rc) return rc; }
+  if (dgamma) {
+    AVDF_REQUIRE(dbeta, "layernorm_bwd: dgamma and dbeta must both be requested");
+    int rc = avdf_reduce_slabs2(ws, dgamma, dbeta, G, 2 * (int64_t)C, C, accumulate, st);
+    if (rc) return rc;
+  }
   return AVDF_OK;
 }
 

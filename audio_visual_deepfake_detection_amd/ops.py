@@ -40,8 +40,21 @@ def _timed(tag, flops, fn):
     return r
 
 
-def _conv_tag(kind, K, stride, rows):
-    return f"conv_{kind}_k{K}s{stride}_{'bm128' if rows >= 4096 else 'bm64'}"
+def _pick_tile(B, T, N):
+    """Mirror of pick_tile() in csrc/gemm_conv.hip (only used to label profile records)."""
+    bm, bn = (128, 64, 64, 32), (128, 128, 64, 128)
+    best, best_blocks = 0, -1
+    for c in range(4):
+        blocks = B * -(-T // bm[c]) * -(-N // bn[c])
+        if blocks >= 512:
+            return c
+        if blocks > best_blocks:
+            best, best_blocks = c, blocks
+    return best
+
+
+def _conv_tag(kind, K, stride, B, T, N):
+    return f"conv_{kind}_k{K}s{stride}_{('128x128', '64x128', '64x64', '32x128')[_pick_tile(B, T, N)]}"
 
 
 def _stream():
@@ -89,7 +102,7 @@ class Conv1dFn(torch.autograd.Function):
         need_pre = act != ACT_NONE and any(ctx.needs_input_grad)
         ypre = torch.empty_like(y) if need_pre else None
         fl = 2.0 * B * Tout * Cout * Cin * K
-        _timed(_conv_tag("fwd", K, stride, B * Tout), fl, lambda: check(
+        _timed(_conv_tag("fwd", K, stride, B, Tout, Cout), fl, lambda: check(
             lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
                                 K, stride, act, _stream()), "conv1d_fwd"))
         ctx.save_for_backward(x, w, mask, ypre)
@@ -106,7 +119,7 @@ class Conv1dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             fl = 2.0 * B * Tout * Cout * Cin * K
-            _timed(_conv_tag("dgrad", K, stride, B * Tin), fl, lambda: check(
+            _timed(_conv_tag("dgrad", K, stride, B, Tin, Cin), fl, lambda: check(
                 lib.avdf_conv1d_bwd_data(_p(dy), _p(w), _p(mask), _p(ypre), _p(dx), B, Tin, Cin, Tout, Cout,
                                          K, stride, act, st), "conv1d_bwd_data"))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
