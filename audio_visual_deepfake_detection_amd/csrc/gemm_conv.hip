@@ -526,8 +526,8 @@ inline int pick_tile(int B, int T, int N) {
 struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles; bool small; };
 inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
   WgradPlan p;
-  const int KT = 32;
   p.small = ((int64_t)Cout * Cin * K <= 512 * 1024);
+  const int KT = p.small ? 128 : 64;           // tokens per K-tile (must match the launch below)
   const int bm = p.small ? 64 : 128;
   p.mtiles = cdiv(Cout, bm);
   p.ctiles = cdiv(Cin, 64);
@@ -583,16 +583,18 @@ extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias
     hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_>), grid, dim3(256), 0, st, \
                        x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT);            \
   } while (0)
-#define LAUNCH_FWD_CFG(KS_, S_, KC_)                                \
+  // K-tile depth per tile shape: deep enough that one tile of MFMAs (>= 2-4k cycles) covers the
+  // global-load latency of the next one at ~1 wave per SIMD (small problems -> low occupancy)
+#define LAUNCH_FWD_CFG(KS_, S_, KC0_, KC1_, KC2_, KC3_)             \
   switch (cfg) {                                                    \
-    case 0: LAUNCH_FWD(KS_, S_, KC_, 2, 2, 2, 2); break;            \
-    case 1: LAUNCH_FWD(KS_, S_, KC_, 2, 2, 1, 2); break;            \
-    case 2: LAUNCH_FWD(KS_, S_, KC_, 2, 2, 1, 1); break;            \
-    default: LAUNCH_FWD(KS_, S_, KC_, 1, 4, 1, 1); break;           \
+    case 0: LAUNCH_FWD(KS_, S_, KC0_, 2, 2, 2, 2); break;           \
+    case 1: LAUNCH_FWD(KS_, S_, KC1_, 2, 2, 1, 2); break;           \
+    case 2: LAUNCH_FWD(KS_, S_, KC2_, 2, 2, 1, 1); break;           \
+    default: LAUNCH_FWD(KS_, S_, KC3_, 1, 4, 1, 1); break;          \
   }
-  if (K == 3 && stride == 1) { LAUNCH_FWD_CFG(3, 1, 16) }
-  else if (K == 3 && stride == 2) { LAUNCH_FWD_CFG(3, 2, 16) }
-  else { LAUNCH_FWD_CFG(1, 1, 32) }
+  if (K == 3 && stride == 1) { LAUNCH_FWD_CFG(3, 1, 32, 32, 64, 32) }
+  else if (K == 3 && stride == 2) { LAUNCH_FWD_CFG(3, 2, 32, 32, 64, 32) }
+  else { LAUNCH_FWD_CFG(1, 1, 64, 64, 128, 64) }
 #undef LAUNCH_FWD_CFG
 #undef LAUNCH_FWD
   AVDF_CHECK_LAUNCH("conv1d_fwd");
@@ -618,16 +620,16 @@ extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float
     hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_>), grid, dim3(256), 0, st, \
                        dy, w, mask, ypre, dx, B, Tin, Cin, Tout, Cout, act, tilesT);                 \
   } while (0)
-#define LAUNCH_DG_CFG(KS_, S_, KC_)                                 \
+#define LAUNCH_DG_CFG(KS_, S_, KC0_, KC1_, KC2_, KC3_)              \
   switch (cfg) {                                                    \
-    case 0: LAUNCH_DG(KS_, S_, KC_, 2, 2, 2, 2); break;             \
-    case 1: LAUNCH_DG(KS_, S_, KC_, 2, 2, 1, 2); break;             \
-    case 2: LAUNCH_DG(KS_, S_, KC_, 2, 2, 1, 1); break;             \
-    default: LAUNCH_DG(KS_, S_, KC_, 1, 4, 1, 1); break;            \
+    case 0: LAUNCH_DG(KS_, S_, KC0_, 2, 2, 2, 2); break;            \
+    case 1: LAUNCH_DG(KS_, S_, KC1_, 2, 2, 1, 2); break;            \
+    case 2: LAUNCH_DG(KS_, S_, KC2_, 2, 2, 1, 1); break;            \
+    default: LAUNCH_DG(KS_, S_, KC3_, 1, 4, 1, 1); break;           \
   }
-  if (K == 3 && stride == 1) { LAUNCH_DG_CFG(3, 1, 16) }
-  else if (K == 3 && stride == 2) { LAUNCH_DG_CFG(3, 2, 16) }
-  else { LAUNCH_DG_CFG(1, 1, 32) }
+  if (K == 3 && stride == 1) { LAUNCH_DG_CFG(3, 1, 32, 32, 64, 32) }
+  else if (K == 3 && stride == 2) { LAUNCH_DG_CFG(3, 2, 32, 32, 64, 32) }
+  else { LAUNCH_DG_CFG(1, 1, 64, 64, 128, 64) }
 #undef LAUNCH_DG_CFG
 #undef LAUNCH_DG
   AVDF_CHECK_LAUNCH("conv1d_bwd_data");
@@ -652,18 +654,18 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
   float* target = p.splits > 1 ? ws : dw;
-#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_)                                                        \
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, 32>),                            \
+#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_)                                                   \
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_>),                           \
                      dim3(p.mtiles, p.ctiles, p.splits), dim3(256), 0, st, dy, x, mask, ypre, target, \
                      B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate)
   if (p.small) {
-    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 1, 1);
-    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 1, 1);
-    else LAUNCH_WG(1, 1, 2, 2, 1, 1);
+    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 1, 1, 128);
+    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 1, 1, 128);
+    else LAUNCH_WG(1, 1, 2, 2, 1, 1, 128);
   } else {
-    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 2, 1);
-    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 2, 1);
-    else LAUNCH_WG(1, 1, 2, 2, 2, 1);
+    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 2, 1, 64);
+    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 2, 1, 64);
+    else LAUNCH_WG(1, 1, 2, 2, 2, 1, 64);
   }
 #undef LAUNCH_WG
   AVDF_CHECK_LAUNCH("conv1d_bwd_weight");

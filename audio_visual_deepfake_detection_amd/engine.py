@@ -126,6 +126,7 @@ class TrainStep:
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
+            p.main_grad = p.grad            # backward kernels accumulate here directly (ops._main_grad)
             off += sz
         for n in self.dead:
             named[n].grad = None

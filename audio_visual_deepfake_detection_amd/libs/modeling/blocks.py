@@ -385,7 +385,8 @@ class DeepInterpolator(nn.Module):
             keep = (torch.rand_like(h) >= self.dp1.p).to(h.dtype) / (1.0 - self.dp1.p)
             h = ops.scale_rows(h.reshape(-1, 1), keep.reshape(-1)).view_as(h)
         w = self.conv2.weight
-        return ops.smallconv(h.view(B, 1, -1), w.view(w.shape[0], w.shape[1], 1), self.conv2.bias).view(B, -1)
+        return ops.smallconv(h.view(B, 1, -1), ops.view_param(w, (w.shape[0], w.shape[1], 1)),
+                             self.conv2.bias).view(B, -1)
 
     def forward(self, inputs, mask):
         feat, _ = self.contraction(inputs, mask)

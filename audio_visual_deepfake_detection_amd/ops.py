@@ -82,8 +82,11 @@ def _ws(n, like):
     return torch.empty(max(int(n), 1), dtype=torch.float32, device=like.device)
 
 
-def _acc_or_new(ctx_needs, shape_like):
-    return torch.empty_like(shape_like) if ctx_needs else None
+def _main_grad(t):
+    """Flat-buffer gradient view attached by engine.TrainStep (`param.main_grad`): when present, the
+    backward kernels ACCUMULATE straight into it (accumulate=1) and autograd receives None, so there
+    is no temporary gradient tensor and no aten add per parameter."""
+    return None if t is None else getattr(t, "main_grad", None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -92,6 +95,7 @@ def _acc_or_new(ctx_needs, shape_like):
 class Conv1dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, mask, stride, act):
+        w0, b0 = w, bias
         x, w, bias, mask = _c(x), _c(w), _c(bias), _c(mask)
         B, Tin, Cin = x.shape
         Cout, Cin_w, K = w.shape
@@ -107,6 +111,7 @@ class Conv1dFn(torch.autograd.Function):
                                 K, stride, act, _stream()), "conv1d_fwd"))
         ctx.save_for_backward(x, w, mask, ypre)
         ctx.cfg = (B, Tin, Cin, Tout, Cout, K, stride, act, bias is not None)
+        ctx.main = (_main_grad(w0), _main_grad(b0))
         return y
 
     @staticmethod
@@ -123,14 +128,20 @@ class Conv1dFn(torch.autograd.Function):
                 lib.avdf_conv1d_bwd_data(_p(dy), _p(w), _p(mask), _p(ypre), _p(dx), B, Tin, Cin, Tout, Cout,
                                          K, stride, act, st), "conv1d_bwd_data"))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(w)
-            db = torch.empty(Cout, dtype=w.dtype, device=w.device) if has_bias else None
+            mw, mb = ctx.main
+            acc = 1 if mw is not None else 0
+            dw = mw.view(w.shape) if acc else torch.empty_like(w)
+            db = None
+            if has_bias:
+                db = mb.view(Cout) if acc else torch.empty(Cout, dtype=w.dtype, device=w.device)
             ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K), x)
             fl = 2.0 * B * Tout * Cout * Cin * K
             _timed(f"conv_wgrad_k{K}s{stride}_{'n64' if Cout * Cin * K <= 512 * 1024 else 'n128'}+reduce", fl,
                    lambda: check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws),
-                                                            B, Tin, Cin, Tout, Cout, K, stride, act, 0, st),
+                                                            B, Tin, Cin, Tout, Cout, K, stride, act, acc, st),
                                  "conv1d_bwd_weight"))
+            if acc:
+                dw = db = None
         return dx, dw, db, None, None, None
 
 
@@ -141,8 +152,17 @@ def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE):
 def linear(x2d, w, bias=None, act=ACT_NONE):
     """nn.Linear on [M, Cin] rows via the K=1 conv path (weight [out, in])."""
     M, Cin = x2d.shape
-    y = conv1d(x2d.view(1, M, Cin), w.view(w.shape[0], Cin, 1), bias, None, 1, act)
+    y = conv1d(x2d.view(1, M, Cin), view_param(w, (w.shape[0], Cin, 1)), bias, None, 1, act)
     return y.view(M, w.shape[0])
+
+
+def view_param(p, shape):
+    """Reshaped view of a parameter that keeps its `main_grad` target (see _main_grad)."""
+    v = p.view(shape)
+    mg = getattr(p, "main_grad", None)
+    if mg is not None:
+        v.main_grad = mg
+    return v
 
 
 # --------------------------------------------------------------------------------------------
@@ -166,6 +186,7 @@ class LayerNormFn(torch.autograd.Function):
                                      _p(_c(pe)), _p(_c(mask)), T, _stream()), "layernorm_fwd")
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.cfg = (M, C, int(relu), None if gamma is None else gamma.shape)
+        ctx.main = (_main_grad(gamma), _main_grad(beta))
         return y
 
     @staticmethod
@@ -174,12 +195,18 @@ class LayerNormFn(torch.autograd.Function):
         M, C, relu, gshape = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.empty(C, dtype=x.dtype, device=x.device) if g is not None else None
-        db = torch.empty(C, dtype=x.dtype, device=x.device) if g is not None else None
+        mg, mb = ctx.main
+        acc = 1 if (mg is not None and mb is not None) else 0
+        dg = db = None
+        if g is not None:
+            dg = mg.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
+            db = mb.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
         ws = _ws(lib.avdf_layernorm_bwd_ws(M, C), x)
         check(lib.avdf_layernorm_bwd(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
-                                     M, C, relu, 0, _stream()), "layernorm_bwd")
-        if dg is not None:
+                                     M, C, relu, acc, _stream()), "layernorm_bwd")
+        if acc:
+            dg = db = None
+        elif dg is not None:
             dg, db = dg.view(gshape), db.view(gshape)
         return dx, dg, db, None, None, None, None
 
@@ -194,6 +221,7 @@ def layernorm(x, gamma, beta, eps=1e-5, relu=False, pe=None, mask=None):
 class DwConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, mask, stride):
+        ctx.main = _main_grad(w)
         x, w, mask = _c(x), _c(w), _c(mask)
         B, Tin, C = x.shape
         assert w.shape == (C, 1, 3), w.shape
@@ -211,11 +239,14 @@ class DwConvFn(torch.autograd.Function):
         B, Tin, Tout, C, stride = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        acc = 1 if ctx.main is not None else 0
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ctx.main.view(w.shape) if acc else torch.empty_like(w)
         ws = _ws(lib.avdf_dwconv_bwd_ws(B, Tout, C), x) if dw is not None else None
-        check(lib.avdf_dwconv_bwd(_p(dy), _p(x), _p(w), _p(mask), _p(dx), _p(dw), _p(ws), B, Tin, Tout, C, stride, 0,
+        check(lib.avdf_dwconv_bwd(_p(dy), _p(x), _p(w), _p(mask), _p(dx), _p(dw), _p(ws), B, Tin, Tout, C, stride, acc,
                                   _stream()), "dwconv_bwd")
-        return dx, dw, None, None
+        return dx, (None if acc else dw), None, None
 
 
 def dwconv(x, w, mask=None, stride=1):
@@ -323,6 +354,7 @@ class AffineResidualFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, ma, r, mr, scale, keep):
+        ctx.main = _main_grad(scale)
         a, ma, r, mr, keep = _c(a), _c(ma), _c(r), _c(mr), _c(keep)
         B, T, C = a.shape
         sc = scale.contiguous().view(-1)
@@ -340,11 +372,14 @@ class AffineResidualFn(torch.autograd.Function):
         dout = dout.contiguous()
         da = torch.empty_like(r) if ctx.needs_input_grad[0] else None
         dr = torch.empty_like(r) if ctx.needs_input_grad[2] else None
-        ds = torch.empty_like(sc) if ctx.needs_input_grad[4] else None
+        acc = 1 if ctx.main is not None else 0
+        ds = None
+        if ctx.needs_input_grad[4]:
+            ds = ctx.main.view(-1) if acc else torch.empty_like(sc)
         ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, C), r) if ds is not None else None
         check(lib.avdf_affine_residual_bwd(_p(dout), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(da), _p(dr), _p(ds),
-                                           _p(ws), B, T, C, 0, _stream()), "affine_residual_bwd")
-        return da, None, dr, None, None if ds is None else ds.view(ctx.sshape), None
+                                           _p(ws), B, T, C, acc, _stream()), "affine_residual_bwd")
+        return da, None, dr, None, None if (ds is None or acc) else ds.view(ctx.sshape), None
 
 
 def affine_residual(a, ma, r, mr, scale, keep=None):
@@ -504,6 +539,7 @@ def maxavgpool(x):
 class SmallConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, mask, scale):
+        ctx.main = (_main_grad(w), _main_grad(bias), _main_grad(scale))
         x, w, bias, mask = _c(x), _c(w), _c(bias), _c(mask)
         B, T, Cin = x.shape
         Cout, _, K = w.shape
@@ -521,12 +557,19 @@ class SmallConvFn(torch.autograd.Function):
         B, T, Cin, Cout, K, has_bias, sshape = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w)
-        db = torch.empty(Cout, dtype=w.dtype, device=w.device) if has_bias else None
-        ds = torch.empty(1, dtype=w.dtype, device=w.device) if sc is not None else None
+        mw, mb, ms = ctx.main
+        acc = 1 if (mw is not None and (not has_bias or mb is not None) and (sc is None or ms is not None)) else 0
+        dw = mw.view(w.shape) if acc else torch.empty_like(w)
+        db = ds = None
+        if has_bias:
+            db = mb.view(Cout) if acc else torch.empty(Cout, dtype=w.dtype, device=w.device)
+        if sc is not None:
+            ds = ms.view(1) if acc else torch.empty(1, dtype=w.dtype, device=w.device)
         ws = _ws(lib.avdf_smallconv_bwd_ws(B, T, Cin, Cout, K), x)
         check(lib.avdf_smallconv_bwd(_p(dy), _p(x), _p(w), _p(y), _p(mask), _p(sc), _p(dx), _p(dw), _p(db), _p(ds),
-                                     _p(ws), B, T, Cin, Cout, K, 0, _stream()), "smallconv_bwd")
+                                     _p(ws), B, T, Cin, Cout, K, acc, _stream()), "smallconv_bwd")
+        if acc:
+            return dx, None, None, None, None
         return dx, dw, db, None, None if ds is None else ds.view(sshape)
 
 
