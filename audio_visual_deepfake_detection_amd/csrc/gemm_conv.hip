@@ -8,15 +8,25 @@
 //   dgrad   : dx[(b,t'), c] = sum_{k,n} g[b, (t'+P-k)/S, n] * w[n,c,k]     (M = B*Tin,  N = Cin)
 //   wgrad   : dw[n, (c,k)]  = sum_{b,t} g[b,t,n] * x[b, t*S+k-P, c]        (M = Cout,   N = Cin x K)
 //
-// All three stage their operand tiles through LDS with a register prefetch of the next K-tile
-// (global loads in flight under the MFMA phase), 4 waves per workgroup, each wave owning
-// MI x NI accumulator tiles of 32x32.  MFMA operand maps (one f32 per lane):
-//   A[i = lane&31][k = lane>>5],  B[k = lane>>5][j = lane&31],
+// Structure shared by the three kernels
+//   * a workgroup = KG "K-groups" of 4 waves.  The 4 waves of a group tile the BM x BN output block
+//     (WM x WN waves, MI x NI accumulator tiles of 32x32 each); the KG groups split every K-tile
+//     between them and their partial accumulators are summed through LDS at the end (intra-block
+//     split-K).  The problems of this path are small for a 256-CU chip (6144 x 256 outputs are only
+//     1536 MFMA tiles for 1024 SIMDs), so parallelism has to come from K as well as from M x N;
+//   * operand tiles are staged global -> registers -> LDS with a one-tile register prefetch (the
+//     loads of tile k+1 are in flight under the MFMAs of tile k);
+//   * LDS rows are padded to an odd stride so the per-lane ds_read_b32 operand fetch is conflict-free;
+//   * the k=3 taps reuse ONE haloed activation tile, stride-2 convs read every other LDS row;
+//   * wgrad additionally splits the token dimension over gridDim.z; partial tiles go to slabs that a
+//     vectorised reducer folds (deterministic: no float atomics anywhere).
+// MFMA operand maps (one f32 per lane): A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
 //   D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 //
 // Replaces: MaskedConv1D / nn.Conv1d(k=1) / nn.Linear of libs/modeling/blocks.py:41-63,
 // 957-966, 1291-1297, 1498-1505 and their autograd-generated backward.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,8 +35,9 @@ struct F4Buf { float4 v[N]; };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-
 __device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int round4(int a) { return (a + 3) / 4 * 4; }
 
 // g = dy * mask[row] * act'(pre)
 __device__ __forceinline__ float4 grad_prologue(const float* __restrict__ dy, const float* __restrict__ mask,
@@ -44,45 +55,72 @@ __device__ __forceinline__ float4 grad_prologue(const float* __restrict__ dy, co
   return g;
 }
 
+// sum the accumulators of K-groups 1..KG-1 into group 0 through LDS (`red` aliases the tile buffers)
+template <int NACC, int KG>
+__device__ __forceinline__ void kgroup_reduce(floatx16 (&acc)[NACC], float* red, int kg, int w4, int lane) {
+  if (KG == 1) return;
+  __syncthreads();
+  if (kg > 0) {
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((((kg - 1) * 4 + w4) * NACC + a) * 16 + r) * 64 + lane] = acc[a][r];
+  }
+  __syncthreads();
+  if (kg == 0) {
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] += red[((((g - 1) * 4 + w4) * NACC + a) * 16 + r) * 64 + lane];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ ypre,
     int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(WM * WN == 4, "4 waves per K-group");
+  static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
+  constexpr int NT = 256 * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RA = (BM - 1) * S + KS;
   constexpr int LDA = KC + 1;
   constexpr int KB = KC * KS;
   constexpr int LDB = KB + 1;
   constexpr int A4 = KC / 4, B4 = KB / 4;
-  constexpr int NA = (RA * A4 + 255) / 256, NB = (BN * B4 + 255) / 256;
-  __shared__ float As[RA * LDA];
-  __shared__ float Bs[BN * LDB];
+  constexpr int NA = (RA * A4 + NT - 1) / NT, NB = (BN * B4 + NT - 1) / NT;
+  constexpr int AS = round4(RA * LDA), BSZ = BN * LDB;
+  constexpr int SM = cmax(AS + BSZ, (KG - 1) * BM * BN);
+  constexpr int KCG = KC / KG;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  float* As = smem;
+  float* Bs = smem + AS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
+  const int kg = wid >> 2, w4 = wid & 3;
+  const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / tilesT, t0 = (blockIdx.x % tilesT) * BM;
   const int n0 = blockIdx.y * BN;
 
-  floatx16 acc[MI][NI];
+  floatx16 acc[MI * NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int a = 0; a < MI * NI; ++a)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
   F4Buf<NA> ra;
   F4Buf<NB> rb;
   auto load_tile = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       float4 v = zero4();
       if (q < RA * A4) {
         const int row = q / A4, c = c0 + (q % A4) * 4;
@@ -93,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       float4 v = zero4();
       if (q < BN * B4) {
         const int n = n0 + q / B4, e = c0 * KS + (q % B4) * 4;
@@ -105,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < RA * A4) {
         float* d = As + (q / A4) * LDA + (q % A4) * 4;
         d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
@@ -113,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < BN * B4) {
         float* d = Bs + (q / B4) * LDB + (q % B4) * 4;
         d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
@@ -127,22 +165,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
+    const float* Ag = As + kg * KCG;
+    const float* Bg = Bs + kg * KCG * KS;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
 #pragma unroll
-      for (int cc = 0; cc < KC; cc += 2) {
+      for (int cc = 0; cc < KCG; cc += 2) {
         float a[MI], bv[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          a[mi] = As[(((wm * MI + mi) * 32 + li) * S + k) * LDA + cc + lh];
+          a[mi] = Ag[(((wm * MI + mi) * 32 + li) * S + k) * LDA + cc + lh];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          bv[ni] = Bs[((wn * NI + ni) * 32 + li) * LDB + (cc + lh) * KS + k];
+          bv[ni] = Bg[((wn * NI + ni) * 32 + li) * LDB + (cc + lh) * KS + k];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -151,6 +191,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
       __syncthreads();
     }
   }
+  kgroup_reduce<MI * NI, KG>(acc, smem, kg, w4, lane);
+  if (kg != 0) return;
 
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -164,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
         const int t = t0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (t >= Tout) continue;
         const size_t row = (size_t)b * Tout + t;
-        float v = acc[mi][ni][r] + bn;
+        float v = acc[mi * NI + ni][r] + bn;
         if (ypre) ypre[row * Cout + n] = v;
         v = act_f(v, act);
         if (mask) v *= mask[row];
@@ -177,35 +219,40 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 // data gradient
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC>
-__global__ __launch_bounds__(256) void conv_dgrad_kernel(
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
     const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ mask,
     const float* __restrict__ ypre, float* __restrict__ dx,
     int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(WM * WN == 4, "4 waves per K-group");
+  static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
+  constexpr int NT = 256 * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RA = (BM + KS - 2) / S + 2;
   constexpr int LDA = KC + 1;
   constexpr int LDB = BN * KS;
   constexpr int A4 = KC / 4, B4 = LDB / 4;
-  constexpr int NA = (RA * A4 + 255) / 256, NB = (KC * B4 + 255) / 256;
-  __shared__ float As[RA * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[KC * LDB];
+  constexpr int NA = (RA * A4 + NT - 1) / NT, NB = (KC * B4 + NT - 1) / NT;
+  constexpr int AS = round4(RA * LDA), BSZ = KC * LDB;
+  constexpr int SM = cmax(AS + BSZ, (KG - 1) * BM * BN);
+  constexpr int KCG = KC / KG;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  float* As = smem;
+  float* Bs = smem + AS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
+  const int kg = wid >> 2, w4 = wid & 3;
+  const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / tilesT, tp0 = (blockIdx.x % tilesT) * BM;
   const int c0 = blockIdx.y * BN;
   const int tA0 = floordiv(tp0 + P - (KS - 1), S);
 
-  floatx16 acc[MI][NI];
+  floatx16 acc[MI * NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int a = 0; a < MI * NI; ++a)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
   // per (mi, k): LDS row of the dy tile this lane's output row reads, or -1 (stride-2 parity miss)
   int arow[MI][KS];
@@ -225,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
   auto load_tile = [&](int nk0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       float4 v = zero4();
       if (q < RA * A4) {
         const int t = tA0 + q / A4, n = nk0 + (q % A4) * 4;
@@ -238,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       float4 v = zero4();
       if (q < KC * B4) {
         const int n = nk0 + q / B4, e = c0 * KS + (q % B4) * 4;
@@ -250,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < RA * A4) {
         float* d = As + (q / A4) * LDA + (q % A4) * 4;
         d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
@@ -258,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < KC * B4) *reinterpret_cast<float4*>(Bs + (q / B4) * LDB + (q % B4) * 4) = rb.v[i];
     }
   };
@@ -269,24 +316,26 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
+    const float* Ag = As + kg * KCG;
+    const float* Bg = Bs + kg * KCG * LDB;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
 #pragma unroll
-      for (int nn = 0; nn < KC; nn += 2) {
+      for (int nn = 0; nn < KCG; nn += 2) {
         float a[MI], bv[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int r = arow[mi][k];
-          a[mi] = r >= 0 ? As[r * LDA + nn + lh] : 0.f;
+          a[mi] = r >= 0 ? Ag[r * LDA + nn + lh] : 0.f;
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          bv[ni] = Bs[(nn + lh) * LDB + ((wn * NI + ni) * 32 + li) * KS + k];
+          bv[ni] = Bg[(nn + lh) * LDB + ((wn * NI + ni) * 32 + li) * KS + k];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -295,6 +344,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
       __syncthreads();
     }
   }
+  kgroup_reduce<MI * NI, KG>(acc, smem, kg, w4, lane);
+  if (kg != 0) return;
 
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -306,30 +357,38 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(
       for (int r = 0; r < 16; ++r) {
         const int tp = tp0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (tp >= Tin) continue;
-        dx[((size_t)b * Tin + tp) * Cin + c] = acc[mi][ni][r];
+        dx[((size_t)b * Tin + tp) * Cin + c] = acc[mi * NI + ni][r];
       }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// weight gradient (split over the token dimension; partial tiles go to slabs)
+// weight gradient (token dimension split over gridDim.z AND over the K-groups of a workgroup)
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mask,
     const float* __restrict__ ypre, float* __restrict__ out,
     int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip, int tilesPerSplit,
     int accumulate) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(WM * WN == 4, "4 waves per K-group");
+  static_assert(KT % (2 * KG) == 0, "token tile must split evenly into pairs per group");
+  constexpr int NT = 256 * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RX = (KT - 1) * S + KS;
   constexpr int Y4 = BM / 4, X4 = BN / 4;
-  constexpr int NY = (KT * Y4 + 255) / 256, NX = (RX * X4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float Ys[KT * BM];
-  __shared__ __attribute__((aligned(16))) float Xs[RX * BN];
+  constexpr int NY = (KT * Y4 + NT - 1) / NT, NX = (RX * X4 + NT - 1) / NT;
+  constexpr int NACC = MI * NI * KS;
+  constexpr int YS = KT * BM, XS = RX * BN;
+  constexpr int SM = cmax(YS + XS, (KG - 1) * 4 * NACC * 1024);
+  constexpr int KTG = KT / KG;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  float* Ys = smem;
+  float* Xs = smem + YS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
+  const int kg = wid >> 2, w4 = wid & 3;
+  const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BM, c0 = blockIdx.y * BN;
   const int gbeg = blockIdx.z * tilesPerSplit;
@@ -337,15 +396,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const int gtot = B * tilesPerClip;
   if (gend > gtot) gend = gtot;
 
-  floatx16 acc[MI][NI][KS];
+  floatx16 acc[NACC];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][k][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
   F4Buf<NY> ry;
   F4Buf<NX> rx;
@@ -353,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const int b = g / tilesPerClip, tt0 = (g % tilesPerClip) * KT;
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       float4 v = zero4();
       if (q < KT * Y4) {
         const int t = tt0 + q / Y4, n = n0 + (q % Y4) * 4;
@@ -366,7 +421,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       float4 v = zero4();
       if (q < RX * X4) {
         const int tr = tt0 * S - P + q / X4, c = c0 + (q % X4) * 4;
@@ -378,12 +433,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < KT * Y4) *reinterpret_cast<float4*>(Ys + (q / Y4) * BM + (q % Y4) * 4) = ry.v[i];
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int q = tid + i * 256;
+      const int q = tid + i * NT;
       if (q < RX * X4) *reinterpret_cast<float4*>(Xs + (q / X4) * BN + (q % X4) * 4) = rx.v[i];
     }
   };
@@ -396,7 +451,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   for (int g = gbeg; g < gend; ++g) {
     if (g + 1 < gend) load_tile(g + 1);
 #pragma unroll
-    for (int tl = 0; tl < KT; tl += 2) {
+    for (int tl0 = 0; tl0 < KTG; tl0 += 2) {
+      const int tl = kg * KTG + tl0;
       float a[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) a[mi] = Ys[(tl + lh) * BM + (wm * MI + mi) * 32 + li];
@@ -407,7 +463,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
           const float bv = Xs[((tl + lh) * S + k) * BN + (wn * NI + ni) * 32 + li];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            acc[mi][ni][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv, acc[mi][ni][k], 0, 0, 0);
+            acc[(mi * NI + ni) * KS + k] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv, acc[(mi * NI + ni) * KS + k], 0, 0, 0);
         }
     }
     __syncthreads();
@@ -416,6 +473,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       __syncthreads();
     }
   }
+  kgroup_reduce<NACC, KG>(acc, smem, kg, w4, lane);
+  if (kg != 0) return;
 
   float* o = out + (gridDim.z > 1 ? (size_t)blockIdx.z * Cout * Cin * KS : 0);
   const bool add = accumulate && gridDim.z == 1;
@@ -432,8 +491,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         float* d = o + ((size_t)n * Cin + c) * KS;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          if (add) d[k] += acc[mi][ni][k][r];
-          else d[k] = acc[mi][ni][k][r];
+          if (add) d[k] += acc[(mi * NI + ni) * KS + k][r];
+          else d[k] = acc[(mi * NI + ni) * KS + k][r];
         }
       }
     }
@@ -507,23 +566,35 @@ constexpr int kColsumBlocks = 128;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Output-tile choice for the forward / dgrad GEMMs.  The problems are small for a 256-CU chip
-// (e.g. 6144 x 256 outputs = 1536 MFMA tiles for 1024 SIMDs), so the largest tile that still yields
-// >= 2 workgroups per CU wins; otherwise the shape with the most workgroups.
-// 0: 128x128  1: 64x128  2: 64x64  3: 32x128
-inline int pick_tile(int B, int T, int N) {
+// Output-tile and K-group choice for the forward / dgrad GEMMs: the largest tile that still yields
+// >= 2 workgroups per CU wins, otherwise the shape with the most workgroups; then as many K-groups
+// as needed to put ~1024+ wave-quads on the chip.
+// tile 0: 128x128  1: 64x128  2: 64x64  3: 32x128
+struct TilePlan { int tile, kg; };
+inline TilePlan pick_tile(int B, int T, int N) {
   const int bm[4] = {128, 64, 64, 32}, bn[4] = {128, 128, 64, 128};
-  int best = 0;
+  TilePlan p{0, 1};
   long best_blocks = -1;
   for (int c = 0; c < 4; ++c) {
     const long blocks = (long)B * cdiv(T, bm[c]) * cdiv(N, bn[c]);
-    if (blocks >= 512) return c;
-    if (blocks > best_blocks) { best_blocks = blocks; best = c; }
+    if (blocks >= 512) { p.tile = c; best_blocks = blocks; break; }
+    if (blocks > best_blocks) { best_blocks = blocks; p.tile = c; }
   }
-  return best;
+  const int maxkg = (p.tile == 0) ? 1 : (p.tile == 1 ? 2 : 4);
+  p.kg = 1;
+  while (p.kg < maxkg && best_blocks * p.kg < 1024) p.kg *= 2;
+  // tuning overrides for tools/gemm_bench.py (never set in production)
+  static const char* ft = getenv("AVDF_FORCE_TILE");
+  static const char* fk = getenv("AVDF_FORCE_KG");
+  if (ft) p.tile = atoi(ft);
+  if (fk) p.kg = atoi(fk);
+  const int mk = (p.tile == 0) ? 1 : (p.tile == 1 ? 2 : 4);
+  if (p.kg > mk) p.kg = mk;
+  if (p.kg == 3) p.kg = 2;
+  return p;
 }
 
-struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles; bool small; };
+struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles, kg; bool small; };
 inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
   WgradPlan p;
   p.small = ((int64_t)Cout * Cin * K <= 512 * 1024);
@@ -533,7 +604,10 @@ inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
   p.ctiles = cdiv(Cin, 64);
   p.tilesPerClip = cdiv(Tout, KT);
   const int total = B * p.tilesPerClip;
-  int want = cdiv(512, p.mtiles * p.ctiles);
+  const int tiles = p.mtiles * p.ctiles;
+  p.kg = p.small ? (tiles >= 256 ? 1 : (tiles >= 64 ? 2 : 4)) : (tiles >= 256 ? 1 : 2);
+  if (K == 3 && p.kg > 2) p.kg = 2;            // 3 accumulator sets per wave: keep the LDS reduction small
+  int want = cdiv(1024, tiles * p.kg);
   if (want < 1) want = 1;
   if (want > total) want = total;
   p.tilesPerSplit = cdiv(total, want);
@@ -563,6 +637,21 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
   return avdf_reduce_slabs2(ws, out, nullptr, nslab, n, n, accumulate, st);
 }
 
+// K-tile depth per tile shape: deep enough that one tile of MFMAs (>= 2-4k cycles per group) covers
+// the global-load latency of the next one at ~1 wave per SIMD.
+#define AVDF_GEMM_DISPATCH(KS_, S_, KC0_, KC1_, KC2_, KC3_, L)                     \
+  switch (plan.tile * 8 + plan.kg) {                                               \
+    case 0 * 8 + 1: L(KS_, S_, KC0_, 2, 2, 2, 2, 1); break;                        \
+    case 1 * 8 + 1: L(KS_, S_, KC1_, 2, 2, 1, 2, 1); break;                        \
+    case 1 * 8 + 2: L(KS_, S_, KC1_, 2, 2, 1, 2, 2); break;                        \
+    case 2 * 8 + 1: L(KS_, S_, KC2_, 2, 2, 1, 1, 1); break;                        \
+    case 2 * 8 + 2: L(KS_, S_, KC2_, 2, 2, 1, 1, 2); break;                        \
+    case 2 * 8 + 4: L(KS_, S_, KC2_, 2, 2, 1, 1, 4); break;                        \
+    case 3 * 8 + 1: L(KS_, S_, KC3_, 1, 4, 1, 1, 1); break;                        \
+    case 3 * 8 + 2: L(KS_, S_, KC3_, 1, 4, 1, 1, 2); break;                        \
+    default: L(KS_, S_, KC3_, 1, 4, 1, 1, 4); break;                               \
+  }
+
 extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const float* mask,
                                float* y, float* ypre, int B, int Tin, int Cin, int Tout, int Cout,
                                int K, int stride, int act, void* stream) {
@@ -574,28 +663,18 @@ extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd: Tout=%d inconsistent with Tin=%d K=%d s=%d", Tout, Tin, K, stride);
   AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd: x/w must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = pick_tile(B, Tout, Cout);
-#define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_)                                                 \
-  do {                                                                                              \
-    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                       \
-    const int tilesT = cdiv(Tout, BM_);                                                             \
-    dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                         \
-    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_>), grid, dim3(256), 0, st, \
-                       x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT);            \
+  const TilePlan plan = pick_tile(B, Tout, Cout);
+#define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
+  do {                                                                                                  \
+    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
+    const int tilesT = cdiv(Tout, BM_);                                                                 \
+    dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                             \
+    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
+                       0, st, x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT);         \
   } while (0)
-  // K-tile depth per tile shape: deep enough that one tile of MFMAs (>= 2-4k cycles) covers the
-  // global-load latency of the next one at ~1 wave per SIMD (small problems -> low occupancy)
-#define LAUNCH_FWD_CFG(KS_, S_, KC0_, KC1_, KC2_, KC3_)             \
-  switch (cfg) {                                                    \
-    case 0: LAUNCH_FWD(KS_, S_, KC0_, 2, 2, 2, 2); break;           \
-    case 1: LAUNCH_FWD(KS_, S_, KC1_, 2, 2, 1, 2); break;           \
-    case 2: LAUNCH_FWD(KS_, S_, KC2_, 2, 2, 1, 1); break;           \
-    default: LAUNCH_FWD(KS_, S_, KC3_, 1, 4, 1, 1); break;          \
-  }
-  if (K == 3 && stride == 1) { LAUNCH_FWD_CFG(3, 1, 32, 32, 64, 32) }
-  else if (K == 3 && stride == 2) { LAUNCH_FWD_CFG(3, 2, 32, 32, 64, 32) }
-  else { LAUNCH_FWD_CFG(1, 1, 64, 64, 128, 64) }
-#undef LAUNCH_FWD_CFG
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_FWD) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_FWD) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, LAUNCH_FWD) }
 #undef LAUNCH_FWD
   AVDF_CHECK_LAUNCH("conv1d_fwd");
   return AVDF_OK;
@@ -611,26 +690,18 @@ extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_data: Tout inconsistent");
   AVDF_REQUIRE(aligned16(dy) && aligned16(w) && (!ypre || aligned16(ypre)), "conv1d_bwd_data: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = pick_tile(B, Tin, Cin);
-#define LAUNCH_DG(KS_, S_, KC_, WM_, WN_, MI_, NI_)                                                   \
-  do {                                                                                               \
-    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                        \
-    const int tilesT = cdiv(Tin, BM_);                                                               \
-    dim3 grid(B * tilesT, cdiv(Cin, BN_));                                                           \
-    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_>), grid, dim3(256), 0, st, \
-                       dy, w, mask, ypre, dx, B, Tin, Cin, Tout, Cout, act, tilesT);                 \
+  const TilePlan plan = pick_tile(B, Tin, Cin);
+#define LAUNCH_DG(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                                  \
+  do {                                                                                                    \
+    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                             \
+    const int tilesT = cdiv(Tin, BM_);                                                                    \
+    dim3 grid(B * tilesT, cdiv(Cin, BN_));                                                                \
+    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
+                       0, st, dy, w, mask, ypre, dx, B, Tin, Cin, Tout, Cout, act, tilesT);               \
   } while (0)
-#define LAUNCH_DG_CFG(KS_, S_, KC0_, KC1_, KC2_, KC3_)              \
-  switch (cfg) {                                                    \
-    case 0: LAUNCH_DG(KS_, S_, KC0_, 2, 2, 2, 2); break;            \
-    case 1: LAUNCH_DG(KS_, S_, KC1_, 2, 2, 1, 2); break;            \
-    case 2: LAUNCH_DG(KS_, S_, KC2_, 2, 2, 1, 1); break;            \
-    default: LAUNCH_DG(KS_, S_, KC3_, 1, 4, 1, 1); break;           \
-  }
-  if (K == 3 && stride == 1) { LAUNCH_DG_CFG(3, 1, 32, 32, 64, 32) }
-  else if (K == 3 && stride == 2) { LAUNCH_DG_CFG(3, 2, 32, 32, 64, 32) }
-  else { LAUNCH_DG_CFG(1, 1, 64, 64, 128, 64) }
-#undef LAUNCH_DG_CFG
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_DG) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_DG) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, LAUNCH_DG) }
 #undef LAUNCH_DG
   AVDF_CHECK_LAUNCH("conv1d_bwd_data");
   return AVDF_OK;
@@ -654,19 +725,23 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
   float* target = p.splits > 1 ? ws : dw;
-#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_)                                                   \
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_>),                           \
-                     dim3(p.mtiles, p.ctiles, p.splits), dim3(256), 0, st, dy, x, mask, ypre, target, \
+#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_)                                                        \
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_>),                                \
+                     dim3(p.mtiles, p.ctiles, p.splits), dim3(256 * KG_), 0, st, dy, x, mask, ypre, target,     \
                      B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate)
-  if (p.small) {
-    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 1, 1, 128);
-    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 1, 1, 128);
-    else LAUNCH_WG(1, 1, 2, 2, 1, 1, 128);
-  } else {
-    if (K == 3 && stride == 1) LAUNCH_WG(3, 1, 2, 2, 2, 1, 64);
-    else if (K == 3 && stride == 2) LAUNCH_WG(3, 2, 2, 2, 2, 1, 64);
-    else LAUNCH_WG(1, 1, 2, 2, 2, 1, 64);
+#define LAUNCH_WG_KG(KS_, S_)                                                   \
+  if (p.small) {                                                                \
+    if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 2);                      \
+    else LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 1);                                \
+  } else {                                                                      \
+    if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 2, 1, 64, 2);                       \
+    else LAUNCH_WG(KS_, S_, 2, 2, 2, 1, 64, 1);                                 \
   }
+  if (K == 3 && stride == 1) { LAUNCH_WG_KG(3, 1) }
+  else if (K == 3 && stride == 2) { LAUNCH_WG_KG(3, 2) }
+  else if (p.small && p.kg == 4) { LAUNCH_WG(1, 1, 2, 2, 1, 1, 128, 4); }
+  else { LAUNCH_WG_KG(1, 1) }
+#undef LAUNCH_WG_KG
 #undef LAUNCH_WG
   AVDF_CHECK_LAUNCH("conv1d_bwd_weight");
   if (p.splits > 1) {
