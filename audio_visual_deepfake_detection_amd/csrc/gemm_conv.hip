@@ -365,10 +365,10 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
 // ------------------------------------------------------------------------------------------
 // weight gradient (token dimension split over gridDim.z AND over the K-groups of a workgroup)
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC>
 __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mask,
-    const float* __restrict__ ypre, float* __restrict__ out,
+    const float* __restrict__ ypre, float* __restrict__ out, float* __restrict__ dbias,
     int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip, int tilesPerSplit,
     int accumulate) {
   static_assert(WM * WN == 4, "4 waves per K-group");
@@ -443,6 +443,10 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
     }
   };
 
+  // ATOMIC path: the c-tile-0 workgroups also fold the bias gradient (column sums of the g tile)
+  const bool do_bias = ATOMIC && dbias != nullptr && blockIdx.y == 0 && tid < BM;
+  float bsum = 0.f;
+
   if (gbeg < gend) {
     load_tile(gbeg);
     store_tile();
@@ -450,6 +454,10 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
   __syncthreads();
   for (int g = gbeg; g < gend; ++g) {
     if (g + 1 < gend) load_tile(g + 1);
+    if (do_bias) {
+#pragma unroll 8
+      for (int t = 0; t < KT; ++t) bsum += Ys[t * BM + tid];
+    }
 #pragma unroll
     for (int tl0 = 0; tl0 < KTG; tl0 += 2) {
       const int tl = kg * KTG + tl0;
@@ -473,10 +481,11 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
       __syncthreads();
     }
   }
+  if (do_bias && n0 + tid < Cout) atomicAdd(dbias + n0 + tid, bsum);
   kgroup_reduce<NACC, KG>(acc, smem, kg, w4, lane);
   if (kg != 0) return;
 
-  float* o = out + (gridDim.z > 1 ? (size_t)blockIdx.z * Cout * Cin * KS : 0);
+  float* o = out + ((!ATOMIC && gridDim.z > 1) ? (size_t)blockIdx.z * Cout * Cin * KS : 0);
   const bool add = accumulate && gridDim.z == 1;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -491,7 +500,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
         float* d = o + ((size_t)n * Cin + c) * KS;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          if (add) d[k] += acc[(mi * NI + ni) * KS + k][r];
+          if (ATOMIC) atomicAdd(d + k, acc[(mi * NI + ni) * KS + k][r]);
+          else if (add) d[k] += acc[(mi * NI + ni) * KS + k][r];
           else d[k] = acc[(mi * NI + ni) * KS + k][r];
         }
       }
@@ -724,11 +734,22 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws) && (!ypre || aligned16(ypre)), "conv1d_bwd_weight: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
-  float* target = p.splits > 1 ? ws : dw;
+  // accumulate != 0 (engine path): partial tiles and the bias column sums are added into dw / dbias with
+  // float atomics -- one launch, no slabs; gradients then differ run-to-run in the last bits, like any
+  // atomics-based wgrad.  accumulate == 0: deterministic slabs + reducer.
+  const bool atomic = accumulate != 0;
+  float* target = (p.splits > 1 && !atomic) ? ws : dw;
 #define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_)                                                        \
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_>),                                \
-                     dim3(p.mtiles, p.ctiles, p.splits), dim3(256 * KG_), 0, st, dy, x, mask, ypre, target,     \
-                     B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate)
+  do {                                                                                                          \
+    if (atomic)                                                                                                 \
+      hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, true>),                      \
+                         dim3(p.mtiles, p.ctiles, p.splits), dim3(256 * KG_), 0, st, dy, x, mask, ypre, target, \
+                         dbias, B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);     \
+    else                                                                                                        \
+      hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, false>),                     \
+                         dim3(p.mtiles, p.ctiles, p.splits), dim3(256 * KG_), 0, st, dy, x, mask, ypre, target, \
+                         dbias, B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);     \
+  } while (0)
 #define LAUNCH_WG_KG(KS_, S_)                                                   \
   if (p.small) {                                                                \
     if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 2);                      \
@@ -744,6 +765,7 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
 #undef LAUNCH_WG_KG
 #undef LAUNCH_WG
   AVDF_CHECK_LAUNCH("conv1d_bwd_weight");
+  if (atomic) return AVDF_OK;
   if (p.splits > 1) {
     int rc = avdf_reduce_slabs(ws, dw, p.splits, (int64_t)Cout * Cin * K, accumulate, st);
     if (rc) return rc;

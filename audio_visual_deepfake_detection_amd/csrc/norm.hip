@@ -70,7 +70,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-    float* __restrict__ dx, float* __restrict__ ws, int M, int C, int relu) {
+    float* __restrict__ dx, float* __restrict__ ws, float* __restrict__ dg_atomic, float* __restrict__ db_atomic,
+    int M, int C, int relu) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2][C]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[NV], ab[NV];
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     float s = 0.f;
 #pragma unroll
     for (int w_ = 0; w_ < 4; ++w_) s += red[(size_t)(w_ * 2 + which) * C + c];
-    ws[(size_t)blockIdx.x * 2 * C + i] = s;
+    if (dg_atomic) atomicAdd((which == 0 ? dg_atomic : db_atomic) + c, s);   // accumulate path: no second kernel
+    else ws[(size_t)blockIdx.x * 2 * C + i] = s;
   }
 }
 
@@ -261,12 +263,15 @@ extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* 
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && (!gamma || (aligned16(gamma) && aligned16(beta))), "layernorm_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
   const int G = ln_bwd_blocks(M);
+  const bool atomic = accumulate && dgamma && dbeta;
+  float* dga = atomic ? dgamma : nullptr;
+  float* dba = atomic ? dbeta : nullptr;
 #define LN_BWD(NV_) hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(G), dim3(256), (size_t)8 * C * sizeof(float), st, \
-                                      dy, x, gamma, beta, mean, rstd, dx, ws, M, C, relu)
+                                      dy, x, gamma, beta, mean, rstd, dx, ws, dga, dba, M, C, relu)
   if (C <= 256) LN_BWD(1); else if (C <= 512) LN_BWD(2); else if (C <= 1024) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
   AVDF_CHECK_LAUNCH("layernorm_bwd");
-  if (dgamma) {
+  if (dgamma && !atomic) {
     AVDF_REQUIRE(dbeta, "layernorm_bwd: dgamma and dbeta must both be requested");
     int rc = avdf_reduce_slabs2(ws, dgamma, dbeta, G, 2 * (int64_t)C, C, accumulate, st);
     if (rc) return rc;

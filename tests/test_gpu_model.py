@@ -93,11 +93,18 @@ def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
         assert res["labels"].dtype == torch.int64 and res["scores"].dtype == torch.float32
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID)])
-def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name, over):
+def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name, over, accumulate):
+    """accumulate=False: deterministic slab reductions, autograd owns the gradients.
+    accumulate=True: the engine path -- every backward kernel adds straight into `param.main_grad`
+    (float atomics / fused reductions) and autograd sees None for parameter gradients."""
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
     model, sd, cfg = build(over, int(g["wseed"]))
     model.train()
+    if accumulate:
+        for p in model.parameters():
+            p.main_grad = torch.zeros_like(p)
     for mod in model.modules():                 # same switches as the golden run (drop-path / dropout off)
         if hasattr(mod, "drop_prob"):
             mod.drop_prob = 0.0
@@ -117,7 +124,7 @@ def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name,
         if not key.startswith("grad::"):
             continue
         p = named[key[6:]]
-        flat = p.grad.detach().flatten().cpu()
+        flat = (p.main_grad if accumulate else p.grad).detach().flatten().cpu()
         stride = max(1, flat.numel() // 4096)
         sample = flat[::stride][:4096].double()
         ref = torch.from_numpy(g[key]).double()
@@ -127,7 +134,13 @@ def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name,
         worst = max(worst, rel, rel_sum)
         assert rel < TOL and rel_sum < TOL, (key, rel, rel_sum)
     print(f"[{name}] worst relative gradient error {worst:.3e}")
-    dead = sorted(k for k, p in named.items() if p.grad is None)
+    if accumulate:
+        assert all(p.grad is None for p in named.values()), "accumulate path must not materialise .grad"
+        # a per-level Scale() whose level has no positive point has an exactly-zero (not missing) gradient
+        dead = sorted(k for k, p in named.items() if float(p.main_grad.abs().sum()) == 0.0
+                      and not k.startswith("reg_head.scale."))
+    else:
+        dead = sorted(k for k, p in named.items() if p.grad is None)
     assert len(dead) == int(g["num_dead"]), (len(dead), int(g["num_dead"]))
 
 
