@@ -3,7 +3,8 @@ import torch
 from torch import nn
 
 from .models import register_backbone
-from .blocks import (MaskedConv1D, LayerNorm, TransformerBlock, MutilModelTransformerBlock, get_sinusoid_encoding)
+from .blocks import (MaskedConv1D, LayerNorm, TransformerBlock, MutilModelTransformerBlock, get_sinusoid_encoding,
+                     plan_drop_path)
 from ... import ops
 
 
@@ -74,6 +75,8 @@ class ConvHRLRFullResSelfAttTransformerBackboneRevised(nn.Module):
         return x
 
     def forward(self, x, reco_x, mask):
+        if self.training:
+            plan_drop_path(self, x.shape[0], x.device)
         same = reco_x is None or reco_x is x
         x = self._embed(x, mask)
         reco_x = x if same else self._embed(reco_x, mask)

@@ -103,12 +103,29 @@ class AffineDropPath(nn.Module):
         self.drop_prob = drop_prob
 
     def sample_keep(self, batch, device):
-        """floor(keep_prob + U[0,1)) / keep_prob per sample (blocks.py:1403-1409); None when inactive."""
+        """floor(keep_prob + U[0,1)) / keep_prob per sample (blocks.py:1403-1409); None when inactive.
+        `plan_drop_path` may have pre-drawn the factors of every module of a network in one launch."""
         if self.drop_prob == 0.0 or not self.training:
             return None
+        pre = getattr(self, "_planned_keep", None)
+        if pre is not None:
+            self._planned_keep = None
+            return pre
         keep_prob = 1 - self.drop_prob
         m = (keep_prob + torch.rand((batch,), dtype=torch.float32, device=device)).floor_()
         return m / keep_prob
+
+
+def plan_drop_path(root, batch, device):
+    """Draw the per-sample keep factors of ALL active AffineDropPath modules under `root` with one
+    torch.rand (3 launches per step instead of 4 per module)."""
+    mods = [m for m in root.modules() if isinstance(m, AffineDropPath) and m.training and m.drop_prob > 0.0]
+    if not mods:
+        return
+    kp = torch.tensor([1.0 - m.drop_prob for m in mods], dtype=torch.float32, device=device)[:, None]
+    keep = (kp + torch.rand((len(mods), batch), dtype=torch.float32, device=device)).floor_() / kp
+    for i, m in enumerate(mods):
+        m._planned_keep = keep[i]
 
 
 class _MHCABase(nn.Module):
