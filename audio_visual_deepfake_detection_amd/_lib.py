@@ -55,6 +55,7 @@ SIGNATURES = {
     "avdf_loc_losses_ws": (L, [I, I]),
     "avdf_loc_assign": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
     "avdf_loc_losses": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, F, P]),
+    "avdf_focal_loss_sum": (I, [P, P, P, P, L, P]),
     "avdf_decode_nms": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, F, F, I, P]),
     "avdf_nms1d_host": (I, [P, P, L, F, P, P]),
     "avdf_sumsq_ws": (L, []),

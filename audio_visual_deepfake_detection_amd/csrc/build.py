@@ -1,6 +1,7 @@
 """Builds libavdf_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m audio_visual_deepfake_detection_amd.csrc.build [--force] [--verbose]
+    python audio_visual_deepfake_detection_amd/csrc/build.py [--force]
+(run it by path: importing the package needs an up-to-date .so)
 """
 import os
 import subprocess

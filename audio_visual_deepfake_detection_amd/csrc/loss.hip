@@ -165,7 +165,36 @@ __global__ void loc_finalize_kernel(const float* __restrict__ partial, int nbloc
   out[4] = num_pos[0];
 }
 
+// generic sum-reduced sigmoid focal loss (alpha .25, gamma 2) over n elements, optional gradient
+__global__ __launch_bounds__(1024) void focal_sum_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                         float* __restrict__ out, float* __restrict__ dx, long n) {
+  __shared__ float red[1024];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    float l, g;
+    focal(x[i], t[i], l, g);
+    s += l;
+    if (dx) dx[i] = g;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
 }  // namespace
+
+// sigmoid_focal_loss(x, t, reduction='sum') of libs/modeling/losses.py:5-53 (single workgroup: used for the
+// [n_fake, T] frame-level loss of exp13, av_fd_no_recon2.py:718-725); dx (optional) = d(sum)/dx.
+extern "C" int avdf_focal_loss_sum(const float* x, const float* t, float* out, float* dx, int64_t n, void* stream) {
+  AVDF_REQUIRE(x && t && out && n > 0, "focal_loss_sum: bad args");
+  hipLaunchKernelGGL(focal_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, t, out, dx, (long)n);
+  AVDF_CHECK_LAUNCH("focal_loss_sum");
+  return AVDF_OK;
+}
 
 extern "C" int64_t avdf_loc_losses_ws(int B, int P) { return (int64_t)B * P * 3 + kLossBlocks * 2 + 4; }
 

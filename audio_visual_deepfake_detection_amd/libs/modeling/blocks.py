@@ -122,7 +122,12 @@ def plan_drop_path(root, batch, device):
     mods = [m for m in root.modules() if isinstance(m, AffineDropPath) and m.training and m.drop_prob > 0.0]
     if not mods:
         return
-    kp = torch.tensor([1.0 - m.drop_prob for m in mods], dtype=torch.float32, device=device)[:, None]
+    cache = getattr(root, "_drop_path_kp", None)      # device constant: built once (not capturable in a hipGraph)
+    key = tuple(m.drop_prob for m in mods)
+    if cache is None or cache[0] != key or cache[1].device != device:
+        cache = (key, torch.tensor([1.0 - q for q in key], dtype=torch.float32, device=device)[:, None])
+        root._drop_path_kp = cache
+    kp = cache[1]
     keep = (kp + torch.rand((len(mods), batch), dtype=torch.float32, device=device)).floor_() / kp
     for i, m in enumerate(mods):
         m._planned_keep = keep[i]
@@ -408,3 +413,52 @@ class DeepInterpolator(nn.Module):
     def forward(self, inputs, mask):
         feat, _ = self.contraction(inputs, mask)
         return self.classifier(feat)
+
+
+class Extract(nn.Module):
+    """Five stride-1 DownBlocks C -> 1024 -> 512 -> 256 -> 128 -> 64 (blocks.py:1640-1661)."""
+
+    def __init__(self, in_channels, hidden_dims=1024):
+        super().__init__()
+        self.down_1 = DownBlock(in_channels, hidden_dims, stride=1)
+        self.down_2 = DownBlock(hidden_dims, hidden_dims // 2, stride=1)
+        self.down_3 = DownBlock(hidden_dims // 2, hidden_dims // 4, stride=1)
+        self.down_4 = DownBlock(hidden_dims // 4, hidden_dims // 8, stride=1)
+        self.down_5 = DownBlock(hidden_dims // 8, hidden_dims // 16, stride=1)
+
+    def forward(self, x, mask):
+        for blk in (self.down_1, self.down_2, self.down_3, self.down_4, self.down_5):
+            x, mask = blk(x, mask)
+        return x, mask
+
+
+class SegmentandCls(nn.Module):
+    """Frame-level + video-level classifier of exp13 (blocks.py:1663-1721): Extract -> 1x1 conv + IN +
+    LeakyReLU -> Linear(64->1) per frame; video logit = Linear(2->1) of (max, avg) over time."""
+
+    def __init__(self, in_channels, hidden_channels=1024, num_classes=1, norm=True):
+        super().__init__()
+        assert not norm and num_classes == 1
+        self.norm = norm
+        self.contraction = Extract(in_channels, hidden_channels)
+        c = hidden_channels // 16
+        self.conv0 = nn.Sequential(nn.Conv1d(c, c, kernel_size=1, bias=False), nn.InstanceNorm1d(c), nn.LeakyReLU(0.2))
+        self.cls_linear1 = nn.Linear(num_classes * 2, num_classes)
+        self.seg_linear = nn.Linear(c, num_classes)
+        self.bn1 = LayerNorm(hidden_channels)        # constructed by the reference, never used
+        self.dp1 = nn.Dropout(p=0.5)
+
+    def forward(self, inputs, mask):
+        """-> (seg_scores [B, T], cls_scores [B, 1])"""
+        B, T, _ = inputs.shape
+        feat, _ = self.contraction(inputs, mask)
+        x = ops.conv1d(feat, self.conv0[0].weight)
+        x = ops.instnorm_lrelu(x, 1e-5, 0.2)
+        w = self.seg_linear.weight
+        seg = ops.smallconv(x, ops.view_param(w, (w.shape[0], w.shape[1], 1)), self.seg_linear.bias)     # [B,T,1]
+        pooled = ops.maxavgpool(seg)                                                                   # [B,2] (max, avg)
+        # Linear(2 -> 1): the narrow-conv kernel wants Cin % 4 == 0 -> zero-pad input and weight to 4
+        pin = torch.nn.functional.pad(pooled, (0, 2)).view(B, 1, 4)
+        pw = torch.nn.functional.pad(self.cls_linear1.weight, (0, 2)).view(1, 4, 1)
+        cls = ops.smallconv(pin, pw, self.cls_linear1.bias).view(B, 1)
+        return seg.view(B, T), cls

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .models import register_meta_arch, make_backbone, make_neck, make_generator
-from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator
+from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator, SegmentandCls
 from ... import ops
 
 
@@ -152,7 +152,7 @@ class AVPtTransformerRecovery(nn.Module):
                                              num_layers=head_num_layers, empty_cls=train_cfg['head_empty_cls'])
         self.reg_head = PtTransformerRegHead(fpn_dim, head_dim, len(self.fpn_strides), kernel_size=head_kernel_size,
                                              num_layers=head_num_layers, with_ln=head_with_ln)
-        self.interpolator = DeepInterpolator(input_dim, embd_dim, norm=False)
+        self._build_front(input_dim, embd_dim)
 
         # EMA of #foreground (av_fd_no_recon.py:321-322).  Kept on the device so a training step has no
         # host sync; `loss_normalizer` (python float in the reference) is exposed as a property.
@@ -163,6 +163,15 @@ class AVPtTransformerRecovery(nn.Module):
         self.num_pos_hook = None                # data-parallel: all-reduce of the positive count
         self.max_gt_per_clip = 16
         self.last_debug = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _build_front(self, input_dim, embd_dim):
+        """Video-level branch in front of the backbone (av_fd_no_recon.py:317)."""
+        self.interpolator = DeepInterpolator(input_dim, embd_dim, norm=False)
+
+    def _front(self, x, mask):
+        """-> (video logits [B,1], reco_x for the backbone or None, extras for the losses)"""
+        return self.interpolator(x, mask), None, None
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -216,8 +225,8 @@ class AVPtTransformerRecovery(nn.Module):
     def forward_features(self, x, mask):
         """Network body on time-major tensors: returns (logits [B,P], offsets [B,P,2], pmask [B,P],
         video logits [B,1], per-level lengths)."""
-        cls_scores = self.interpolator(x, mask)
-        feats, masks = self.backbone(x, None, mask)
+        cls_scores, reco_x, self._front_extra = self._front(x, mask)
+        feats, masks = self.backbone(x, reco_x, mask)
         fpn_feats, fpn_masks = self.neck(feats, masks)
         out_cls = self.cls_head(fpn_feats, fpn_masks)
         out_off = self.reg_head(fpn_feats, fpn_masks)
@@ -232,7 +241,8 @@ class AVPtTransformerRecovery(nn.Module):
         points = torch.cat(self.point_generator(lens), dim=0)
         if self.training:
             gt, ngt = self._pack_gt(video_list, x.device)
-            return self.losses(points, logits, offsets, pmask, cls_scores, gt, ngt)
+            losses = self.losses(points, logits, offsets, pmask, cls_scores, gt, ngt)
+            return self._extra_losses(losses, video_list)
         return self.inference(video_list, points, pmask, logits, offsets, cls_scores, lens)
 
     # ------------------------------------------------------------------------------------------
@@ -261,6 +271,9 @@ class AVPtTransformerRecovery(nn.Module):
         self.last_debug['num_pos'] = det[4]
         return {'cls_loss': det[0], 'reg_loss': det[1], 'reco_cls_loss': det[2], 'final_loss': out[3]}
 
+    def _extra_losses(self, losses, video_list):
+        return losses
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def inference(self, video_list, points, pmask, logits, offsets, cls_scores, lens):
@@ -288,3 +301,32 @@ class AVPtTransformerRecovery(nn.Module):
                             'labels': torch.zeros(n, dtype=torch.int64), 'video_cls': video_cls[b],
                             'kept_points': pidx[b, :n].to(torch.int64)})
         return results
+
+
+@register_meta_arch("AVLocPointTransformerRecoveryNoNormNoreconTHE")
+class AVPtTransformerRecoveryTHE(AVPtTransformerRecovery):
+    """exp13 model (configs_train/deepfake_exp13.yaml; reference: libs/modeling/av_fd_no_recon2.py):
+    `SegmentandCls` replaces `DeepInterpolator`; an extra frame-level focal loss `reco_seg_loss` is
+    REPORTED but not part of `final_loss` (av_fd_no_recon2.py:718-733)."""
+
+    def _build_front(self, input_dim, embd_dim):
+        self.segmentandCls = SegmentandCls(input_dim, norm=False)
+
+    def _front(self, x, mask):
+        seg_scores, cls_scores = self.segmentandCls(x, mask)
+        return cls_scores, None, seg_scores
+
+    def _extra_losses(self, losses, video_list):
+        seg_scores = self._front_extra.detach()
+        idx = [b for b, v in enumerate(video_list) if v['segments'] is not None]
+        T = seg_scores.shape[1]
+        if idx:
+            gt = torch.zeros((len(idx), T), dtype=torch.float32)
+            for j, b in enumerate(idx):
+                fl = video_list[b]['gt_frame_labels'].to(torch.float32).reshape(-1)
+                gt[j, :fl.numel()] = fl
+            s = ops.focal_loss_sum(seg_scores[idx].contiguous(), gt.to(seg_scores.device))
+            losses['reco_seg_loss'] = (s / (self._loss_norm_state * 10.0)).reshape(())
+        else:
+            losses['reco_seg_loss'] = torch.zeros((), device=seg_scores.device)
+        return losses

@@ -635,6 +635,26 @@ def loc_losses(logits, offsets, video_logits, points, pmask, gt, ngt, state, cfg
     return LocLossFn.apply(logits, offsets, video_logits, points, pmask, gt, ngt, state, cfg, num_pos_hook)
 
 
+class FocalSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        x, t = _c(x), _c(t)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(lib.avdf_focal_loss_sum(_p(x), _p(t), _p(out), _p(dx), x.numel(), _stream()), "focal_loss_sum")
+        ctx.save_for_backward(dx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None
+
+
+def focal_loss_sum(x, t):
+    return FocalSumFn.apply(x, t)
+
+
 # --------------------------------------------------------------------------------------------
 # decode + NMS
 # --------------------------------------------------------------------------------------------

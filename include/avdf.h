@@ -173,6 +173,10 @@ int avdf_loc_losses(const float* logits, const float* offsets, const float* pmas
                     float* ws_partial, int B, int P, float label_smoothing, float loss_weight,
                     float video_weight, float momentum, void* stream);
 
+/* sigmoid_focal_loss(x, t, reduction='sum') (losses.py:5-53, alpha .25, gamma 2) over n elements; dx optional.
+ * Used for the frame-level loss of exp13 (av_fd_no_recon2.py:718-725).                               */
+int avdf_focal_loss_sum(const float* x, const float* t, float* out, float* dx, int64_t n, void* stream);
+
 /* ---- decode + 1-D NMS + voting, batched over clips (device) ------------------------------
  * inference_single_video (av_fd_no_recon.py:760-825) + batched_nms/NMSop/seg_voting
  * (libs/utils/nms.py:8-35,67-190) + nms_1d_cpu (libs/utils/csrc/nms_cpu.cpp:19-58).

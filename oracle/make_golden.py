@@ -61,7 +61,8 @@ def synth_inputs(cfg, lens, seed):
 def ref_forward_heads(model, x, mask_f):
     """Replays av_fd_no_recon.py:346-379 on pre-batched tensors (so B>1 works in eval)."""
     mb = mask_f > 0
-    norm_inputs, reco, cls_scores = model.interpolator(x, mb)
+    front = model.interpolator if hasattr(model, "interpolator") else model.segmentandCls
+    norm_inputs, reco, cls_scores = front(x, mb)
     feats, masks = model.backbone(x, norm_inputs, x, mb)
     fpn_feats, fpn_masks = model.neck(feats, masks)
     logits = [t.permute(0, 2, 1) for t in model.cls_head(fpn_feats, fpn_masks)]
@@ -86,9 +87,13 @@ def match_segments(seg_a, sc_a, seg_b, sc_b):
     return maxdiff(seg_a, seg_b[perm]), maxdiff(sc_a, sc_b[perm]), perm
 
 
+def yaml_for(cfg):
+    return {"norecon": "deepfake_exp10.yaml", "the": "deepfake_exp13.yaml", "recon": "deepfake_exp5.yaml"}[cfg["variant"]]
+
+
 def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_levels=True):
     load_config, C, make_meta_arch = ctx
-    model, _ = ref_model(load_config, C, make_meta_arch, "deepfake_exp10.yaml", cfg)
+    model, _ = ref_model(load_config, C, make_meta_arch, yaml_for(cfg), cfg)
     shapes = R.param_shapes(cfg)
     ref_sd = model.state_dict()
     assert set(shapes) == set(ref_sd), (set(shapes) ^ set(ref_sd))
@@ -151,17 +156,19 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
     """Training-mode losses + a few gradients with drop-path / dropout disabled
     (drop_prob=0 -> drop_path is the identity, blocks.py:1401-1402)."""
     load_config, C, make_meta_arch = ctx
-    model, _ = ref_model(load_config, C, make_meta_arch, "deepfake_exp10.yaml", cfg)
+    model, _ = ref_model(load_config, C, make_meta_arch, yaml_for(cfg), cfg)
     sd = R.synth_state_dict(R.param_shapes(cfg), wseed, True)
     model.load_state_dict(sd, strict=True)
     model.train()
     for mod in model.modules():
         if hasattr(mod, "drop_prob"):
             mod.drop_prob = 0.0
-    model.interpolator.dp1.p = 0.0
+    if hasattr(model, "interpolator"):
+        model.interpolator.dp1.p = 0.0
+    the = cfg["variant"] == "the"
     x, mask = synth_inputs(cfg, lens, xseed)
     rs = np.random.RandomState(xseed + 7)
-    vids, gts, gls = [], [], []
+    vids, gts, gls, gfl = [], [], [], []
     for b, n in enumerate(lens):
         if b % 2 == 0:
             k = 1 + b % 3
@@ -173,16 +180,23 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
             seg, lab = None, None
         gts.append(seg)
         gls.append(lab)
+        fl = None
+        if seg is not None:
+            fl = torch.zeros(cfg["max_seq_len"])
+            for a_, b_ in seg.tolist():
+                fl[int(a_):int(b_) + 1] = 1.0
+        gfl.append(fl)
         vids.append(dict(video_id=f"c{b}", feats=x[b, :, :n].clone(), segments=seg, labels=lab, fps=25.0,
-                         duration=n / 25.0, feat_stride=1.0, feat_num_frames=1.0))
+                         duration=n / 25.0, feat_stride=1.0, feat_num_frames=1.0, gt_frame_labels=fl))
     losses = model(vids)
     losses["final_loss"].backward()
     # oracle
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = R.model_forward(sdg, cfg, x, mask, training=True)
-    ol, norm, npos = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"])
+    ol, norm, npos = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], gt_frame_labels=gfl if the else None)
     ol["final_loss"].backward()
-    for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss"):
+    lkeys = ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss") + (("reco_seg_loss",) if the else ())
+    for k in lkeys:
         print(f"[{name}] {k}: ref {float(losses[k]):.6f} oracle {float(ol[k]):.6f}")
         assert abs(float(losses[k]) - float(ol[k])) < 1e-4 * max(1.0, abs(float(losses[k])))
     assert abs(norm - model.loss_normalizer) < 1e-6
@@ -190,8 +204,14 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
              "backbone.branch.4.attn.value_conv.conv.weight", "backbone.lh_branch.2.mlp.3.weight",
              "backbone.hh_branch.0.attn.key_norm.weight", "backbone.branch.1.drop_path_attn.scale",
              "neck.fpn_convs.3.conv.weight", "cls_head.cls_head.conv.bias", "reg_head.scale.2.scale",
-             "reg_head.offset_head.conv.weight", "interpolator.contraction.down_3.conv_block.conv.weight",
-             "interpolator.conv1.weight", "interpolator.bn1.bias"]
+             "reg_head.offset_head.conv.weight"]
+    if the:
+        gkeys += ["segmentandCls.contraction.down_3.conv_block.conv.weight", "segmentandCls.conv0.0.weight",
+                  "segmentandCls.seg_linear.weight", "segmentandCls.cls_linear1.weight",
+                  "segmentandCls.cls_linear1.bias", "segmentandCls.contraction.down_1.conv_block.conv.bias"]
+    else:
+        gkeys += ["interpolator.contraction.down_3.conv_block.conv.weight", "interpolator.conv1.weight",
+                  "interpolator.bn1.bias"]
     named = dict(model.named_parameters())
     store = {}
     worst = 0.0
@@ -213,6 +233,8 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
                              dtype=object),
         is_fake=np.array([g is not None for g in gts]),
         losses=np.array([float(losses[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")]),
+        reco_seg_loss=float(losses["reco_seg_loss"]) if the else 0.0,
+        gt_frame_labels=np.array([np.zeros(0, np.float32) if f is None else f.numpy() for f in gfl], dtype=object),
         loss_normalizer=float(model.loss_normalizer), num_dead=len(dead),
         dead_prefixes=np.array(sorted({".".join(d.split(".")[:3]) for d in dead})), **store)
 
@@ -287,6 +309,8 @@ def main():
     case_train("train_small", R.make_cfg(**SMALL), [192, 150, 180, 192], 3, 9, ctx)
     case_train("train_mid", R.make_cfg(**MID), [384, 300, 350, 200], 7, 10, ctx)
     case_forward("fwd_exp10", R.make_cfg(), [768, 700], 21, 22, ctx)
+    case_forward("fwd_the_small", R.make_cfg(variant="the", **SMALL), [192, 133], 31, 32, ctx)
+    case_train("train_the_small", R.make_cfg(variant="the", **SMALL), [192, 150, 180, 192], 33, 34, ctx)
     print("done")
 
 
