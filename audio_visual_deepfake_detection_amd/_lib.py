@@ -58,6 +58,12 @@ SIGNATURES = {
     "avdf_focal_loss_sum": (I, [P, P, P, P, L, P]),
     "avdf_decode_nms": (I, [P, P, P, P, P, P, P, P, I, I, F, F, F, F, F, I, P]),
     "avdf_nms1d_host": (I, [P, P, L, F, P, P]),
+    "avdf_frame_window": (I, [P, P, P, L, I, I, I, P]),
+    "avdf_power_spectrum": (I, [P, P, L, I, P]),
+    "avdf_logmel_norm": (I, [P, P, L, I, F, F, F, P]),
+    "avdf_conv2d_c1_bn_relu_pool": (I, [P, P, P, P, P, I, I, I, P]),
+    "avdf_mel_im2col": (I, [P, P, I, I, I, P]),
+    "avdf_maxpool2x2": (I, [P, P, I, I, I, I, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
     "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),

@@ -192,6 +192,22 @@ int avdf_decode_nms(const float* points, const float* logits, const float* offse
 int avdf_nms1d_host(const float* segs, const float* scores, int64_t n, float iou_thr,
                     int64_t* keep, int64_t* n_keep);
 
+/* ---- audio front-end + BYOL-A encoder glue (frozen extractor, forward only) -------------------------
+ * Reference: audio_feature/content_audio/extract_audio_feature_batch.py:42-60 (torchaudio MelSpectrogram
+ * 16 kHz / n_fft 1024 / hop 160 / 64 mel / 60-7800 Hz, log, PrecomputedNorm) and
+ * audio_feature/content_audio/byol_a/models.py:53-85 (AudioNTT2020Task6).  The STFT (frames x DFT matrix),
+ * the mel projection, conv2/conv3 (as k=3 conv1d over time on mel-im2col'd data) and the two Linear layers
+ * run on avdf_conv1d_fwd; these are the HBM-bound pieces around them.  CNN activations: [M(mel), T, C].   */
+int avdf_frame_window(const float* pcm, const float* window, float* frames, int64_t n_samples,
+                      int n_frames, int n_fft, int hop, void* stream);   /* centre + reflect pad, [F, n_fft] */
+int avdf_power_spectrum(const float* spec /*[F,2*kp]=re|im*/, float* power /*[F,kp]*/, int64_t n_frames, int kp, void* stream);
+int avdf_logmel_norm(const float* mel /*[F,n_mels]*/, float* lms /*[n_mels,F]*/, int64_t n_frames, int n_mels,
+                     float eps, float mean, float stdv, void* stream);
+int avdf_conv2d_c1_bn_relu_pool(const float* x /*[M,T]*/, const float* w /*[C,9]*/, const float* scale,
+                                const float* shift, float* out /*[M/2,T/2,C]*/, int M, int T, int C, void* stream);
+int avdf_mel_im2col(const float* x /*[M,T,C]*/, float* xcol /*[M,T,3C]*/, int M, int T, int C, void* stream);
+int avdf_maxpool2x2(const float* x /*[M,T,C]*/, float* out, int M, int T, int C, int t_major, void* stream);
+
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);
 int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);
