@@ -42,6 +42,11 @@ SIGNATURES = {
     "avdf_downsample_fwd": (I, [P, P, I, I, I, I, P]),
     "avdf_downsample_bwd": (I, [P, P, I, I, I, I, P]),
     "avdf_add_upsampled": (I, [P, P, P, I, I, I, I, P]),
+    "avdf_bias_mask_fwd": (I, [P, P, P, P, L, I, P]),
+    "avdf_masked_colsum_ws": (L, [I]),
+    "avdf_masked_colsum": (I, [P, P, P, P, L, I, I, P]),
+    "avdf_l1_mean_ws": (L, []),
+    "avdf_l1_mean": (I, [P, P, P, P, P, P, I, L, F, P]),
     "avdf_scale_rows": (I, [P, P, P, I, I, P]),
     "avdf_transpose": (I, [P, P, I, I, I, P]),
     "avdf_instnorm_lrelu_fwd": (I, [P, P, P, P, I, I, I, F, F, P]),

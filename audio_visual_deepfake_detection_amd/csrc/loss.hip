@@ -185,7 +185,51 @@ __global__ __launch_bounds__(1024) void focal_sum_kernel(const float* __restrict
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// partial[blockIdx.x] = sum_b wb[b] * sum_i |a[b,i] - b[b,i]|; da = wb[b] * sign(a-b) * inv_denom
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 const float* __restrict__ wb, float* __restrict__ partial,
+                                                 float* __restrict__ da, int B, long per, float inv_denom) {
+  __shared__ float red[256];
+  float s = 0.f;
+  const long total = (long)B * per;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float w_ = wb[i / per];
+    const float d = a[i] - b[i];
+    s += w_ * fabsf(d);
+    if (da) da[i] = w_ * inv_denom * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void l1_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out, float inv_denom) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += partial[i];
+  out[0] = s * inv_denom;
+}
+
 }  // namespace
+
+constexpr int kL1Blocks = 512;
+extern "C" int64_t avdf_l1_mean_ws(void) { return kL1Blocks; }
+
+// L1 reconstruction loss of exp5 on the REAL clips only (av_fd_meta_arch.py:683-686):
+//   out[0] = sum_b wb[b] * sum |a - b| * inv_denom,  da = wb[b] * sign(a - b) * inv_denom   (wb = 1 for real clips)
+extern "C" int avdf_l1_mean(const float* a, const float* b, const float* wb, float* out, float* da, float* ws,
+                            int B, int64_t per_clip, float inv_denom, void* stream) {
+  AVDF_REQUIRE(a && b && wb && out && ws && B > 0 && per_clip > 0, "l1_mean: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_kernel, dim3(kL1Blocks), dim3(256), 0, st, a, b, wb, ws, da, B, (long)per_clip, inv_denom);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, st, ws, kL1Blocks, out, inv_denom);
+  AVDF_CHECK_LAUNCH("l1_mean");
+  return AVDF_OK;
+}
 
 // sigmoid_focal_loss(x, t, reduction='sum') of libs/modeling/losses.py:5-53 (single workgroup: used for the
 // [n_fake, T] frame-level loss of exp13, av_fd_no_recon2.py:718-725); dx (optional) = d(sum)/dx.

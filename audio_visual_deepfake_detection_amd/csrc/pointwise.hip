@@ -343,6 +343,44 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
   }
 }
 
+// y[row, c] = (x[row, c] + bias[c]) * mask[row]   (MaskedConvTranspose1D epilogue, blocks.py:1477-1489)
+__global__ __launch_bounds__(256) void bias_mask_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                        const float* __restrict__ mask, float* __restrict__ y, long M, int C) {
+  const int C4 = C >> 2;
+  const long total = M * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const long row = i / C4;
+    float4 v = ld4(x + row * C + c);
+    if (bias) v = add4(v, ld4(bias + c));
+    if (mask) v = scl4(v, mask[row]);
+    st4(y + row * C + c, v);
+  }
+}
+
+// partial[blockIdx.x][c] = sum over this block's rows of dy[row, c] * mask[row]
+__global__ __launch_bounds__(256) void masked_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                            float* __restrict__ partial, long M, int C) {
+  __shared__ float red[4][256];
+  const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int c = cb + cg * 4;
+    float4 s_ = f4(0.f);
+    if (c < C) {
+      for (long r = (long)blockIdx.x * 4 + rg; r < M; r += (long)gridDim.x * 4) {
+        float4 g = ld4(dy + r * C + c);
+        if (mask) g = scl4(g, mask[r]);
+        s_ = add4(s_, g);
+      }
+    }
+    red[rg][cg * 4 + 0] = s_.x; red[rg][cg * 4 + 1] = s_.y; red[rg][cg * 4 + 2] = s_.z; red[rg][cg * 4 + 3] = s_.w;
+    __syncthreads();
+    if (cb + threadIdx.x < C)
+      partial[(size_t)blockIdx.x * C + cb + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                          float* __restrict__ y, long M, int C) {
   const long total = M * C;
@@ -510,6 +548,29 @@ extern "C" int avdf_downsample_bwd(const float* dy, float* dx, int B, int Tin, i
 extern "C" int avdf_add_upsampled(const float* a, const float* small, float* out, int B, int T, int C, int r, void* stream) {
   AVDF_REQUIRE(a && r > 0 && T % r == 0, "add_upsampled: bad args");
   return resample("add_upsampled", small, a, out, B, T, T / r, C, r, 4, stream);
+}
+
+extern "C" int avdf_bias_mask_fwd(const float* x, const float* bias, const float* mask, float* y, int64_t M, int C, void* stream) {
+  AVDF_REQUIRE(x && y && M > 0 && C > 0, "bias_mask_fwd: bad args");
+  REQ_C4("bias_mask_fwd", C);
+  AVDF_REQUIRE(aligned16(x) && aligned16(y) && (!bias || aligned16(bias)), "bias_mask_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(bias_mask_kernel, dim3(grid_for((long)M * C / 4)), dim3(256), 0, (hipStream_t)stream, x, bias, mask, y, (long)M, C);
+  AVDF_CHECK_LAUNCH("bias_mask_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int64_t avdf_masked_colsum_ws(int C) { return (int64_t)kPartialBlocks * C; }
+
+// out[c] (+)= sum_rows dy[row, c] * mask[row]   (bias gradient of the epilogue above)
+extern "C" int avdf_masked_colsum(const float* dy, const float* mask, float* out, float* ws, int64_t M, int C,
+                                  int accumulate, void* stream) {
+  AVDF_REQUIRE(dy && out && ws && M > 0 && C > 0, "masked_colsum: bad args");
+  REQ_C4("masked_colsum", C);
+  AVDF_REQUIRE(aligned16(dy), "masked_colsum: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(masked_colsum_kernel, dim3(kPartialBlocks), dim3(256), 0, st, dy, mask, ws, (long)M, C);
+  AVDF_CHECK_LAUNCH("masked_colsum");
+  return avdf_reduce_slabs(ws, out, kPartialBlocks, C, accumulate, st);
 }
 
 extern "C" int avdf_scale_rows(const float* x, const float* s, float* y, int M, int C, void* stream) {

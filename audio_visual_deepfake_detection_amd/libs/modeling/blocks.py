@@ -330,8 +330,8 @@ class DownBlock(nn.Module):
 
 
 class MaskedConvTranspose1D(nn.Module):
-    """Parameter holder of the Expansion branch (blocks.py:1443-1491).  Its output is discarded by
-    the exp10/exp12 meta-arch (av_fd_no_recon.py:346-349), so no kernel is attached yet."""
+    """Masked transposed conv (blocks.py:1443-1491): k3 / stride 2 / padding 1 / output_padding 1 doubles T;
+    the mask is nearest-upsampled (each entry repeated).  Runs as the data-gradient of a stride-2 conv."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, dilation=1,
                  groups=1, padding_mode='zeros'):
@@ -341,6 +341,12 @@ class MaskedConvTranspose1D(nn.Module):
         self.conv = nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride, padding,
                                        output_padding=output_padding, dilation=dilation, groups=groups,
                                        padding_mode=padding_mode)
+        self.supported = (kernel_size == 3 and stride == 2 and padding == 1 and output_padding == 1 and groups == 1)
+
+    def forward(self, x, mask):
+        assert self.supported, "only the k3/s2/p1/op1 shape of Expansion (blocks.py:1571-1576) is implemented"
+        out_mask = mask.repeat_interleave(self.stride, dim=1).contiguous()      # F.interpolate(nearest) to 2T
+        return ops.conv_transpose1d_k3s2(x, self.conv.weight, self.conv.bias, out_mask), out_mask
 
 
 class UpBlock(nn.Module):
@@ -350,6 +356,11 @@ class UpBlock(nn.Module):
         self.conv_transpose = MaskedConvTranspose1D(in_channel, out_channel, kernel_size, stride=stride,
                                                     padding=padding, dilation=dilation, output_padding=output_padding)
         self.norm, self.last = norm, last
+        assert norm and not last, "Expansion(tanh=False) builds every UpBlock with IN + LeakyReLU (blocks.py:1599)"
+
+    def forward(self, x, mask):
+        x, mask = self.conv_transpose(x, mask)
+        return ops.instnorm_lrelu(x, 1e-5, 0.2), mask
 
 
 class Contraction(nn.Module):
@@ -375,6 +386,11 @@ class Expansion(nn.Module):
         self.up_3 = UpBlock(hidden_dims // 2, hidden_dims // 4, output_padding=1)
         self.up_4 = UpBlock(hidden_dims // 4, hidden_dims // 8, output_padding=1)
         self.up_5 = UpBlock(hidden_dims // 8, out_channels, output_padding=1, last=tanh)
+
+    def forward(self, x, mask):
+        for blk in (self.up_1, self.up_2, self.up_3, self.up_4, self.up_5):
+            x, mask = blk(x, mask)
+        return x, mask
 
 
 class DeepInterpolator(nn.Module):
@@ -410,9 +426,15 @@ class DeepInterpolator(nn.Module):
         return ops.smallconv(h.view(B, 1, -1), ops.view_param(w, (w.shape[0], w.shape[1], 1)),
                              self.conv2.bias).view(B, -1)
 
-    def forward(self, inputs, mask):
-        feat, _ = self.contraction(inputs, mask)
-        return self.classifier(feat)
+    def forward(self, inputs, mask, need_reco=False):
+        """-> video logits [B, num_classes] (and the reconstruction [B, T, C] when `need_reco`: only exp5
+        consumes the Expansion output, av_fd_meta_arch.py:346-348; exp10/12 discard it)."""
+        feat, fmask = self.contraction(inputs, mask)
+        cls = self.classifier(feat)
+        if not need_reco:
+            return cls
+        reco, _ = self.expansion(feat, fmask)
+        return cls, reco
 
 
 class Extract(nn.Module):

@@ -225,6 +225,7 @@ class AVPtTransformerRecovery(nn.Module):
     def forward_features(self, x, mask):
         """Network body on time-major tensors: returns (logits [B,P], offsets [B,P,2], pmask [B,P],
         video logits [B,1], per-level lengths)."""
+        self._front_input = x
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
         feats, masks = self.backbone(x, reco_x, mask)
         fpn_feats, fpn_masks = self.neck(feats, masks)
@@ -329,4 +330,25 @@ class AVPtTransformerRecoveryTHE(AVPtTransformerRecovery):
             losses['reco_seg_loss'] = (s / (self._loss_norm_state * 10.0)).reshape(())
         else:
             losses['reco_seg_loss'] = torch.zeros((), device=seg_scores.device)
+        return losses
+
+
+@register_meta_arch("AVLocPointTransformerRecoveryNoNorm")
+class AVPtTransformerRecoveryNoNorm(AVPtTransformerRecovery):
+    """exp5 model (configs_train/deepfake_exp5.yaml; reference: libs/modeling/av_fd_meta_arch.py): the
+    Expansion output `reco_result` is the key source of the first cross-attention block (:346-348) and an
+    L1 reconstruction loss on the REAL clips is added to `final_loss` (:683-686,701).  As in the reference,
+    a batch without any real clip makes that mean -- and hence the loss -- NaN."""
+
+    def _front(self, x, mask):
+        cls_scores, reco = self.interpolator(x, mask, need_reco=True)
+        return cls_scores, reco, reco
+
+    def _extra_losses(self, losses, video_list):
+        reco, x = self._front_extra, self._front_input
+        real = [1.0 if v['segments'] is None else 0.0 for v in video_list]
+        wb = torch.tensor(real, dtype=torch.float32).to(x.device)
+        reco_loss = ops.l1_mean(reco, x.detach(), wb, int(sum(real))).reshape(())
+        losses['reco_loss'] = reco_loss.detach()
+        losses['final_loss'] = losses['final_loss'] + reco_loss
         return losses

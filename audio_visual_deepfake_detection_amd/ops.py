@@ -149,6 +149,94 @@ def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE):
     return Conv1dFn.apply(x, w, bias, mask, stride, act)
 
 
+class ConvTranspose1dFn(torch.autograd.Function):
+    """nn.ConvTranspose1d(k=3, stride=2, padding=1, output_padding=1) on time-major tensors + bias + mask:
+    y[b, t', co] = (sum_{ci,k} x[b, t, ci] * w[ci, co, k] + bias[co]) * mask[b, t'],  t' = 2t - 1 + k.
+    This IS the data-gradient of a stride-2 conv whose weight is w read as [Cout_conv = ci, Cin_conv = co, K],
+    so forward = avdf_conv1d_bwd_data, d/dx = avdf_conv1d_fwd and d/dw = avdf_conv1d_bwd_weight with the roles
+    of activation and gradient swapped (MaskedConvTranspose1D, blocks.py:1443-1491)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mask_out):
+        ctx.main = (_main_grad(w), _main_grad(bias))
+        x, w, bias, mask_out = _c(x), _c(w), _c(bias), _c(mask_out)
+        B, T, Ci = x.shape
+        Ci_w, Co, K = w.shape
+        assert Ci_w == Ci and K == 3
+        T2 = 2 * T
+        st = _stream()
+        raw = torch.empty((B, T2, Co), dtype=x.dtype, device=x.device)
+        check(lib.avdf_conv1d_bwd_data(_p(x), _p(w), None, None, _p(raw), B, T2, Co, T, Ci, 3, 2, ACT_NONE, st),
+              "conv_transpose1d_fwd")
+        y = torch.empty_like(raw)
+        check(lib.avdf_bias_mask_fwd(_p(raw), _p(bias), _p(mask_out), _p(y), B * T2, Co, st), "bias_mask_fwd")
+        ctx.save_for_backward(x, w, mask_out)
+        ctx.cfg = (B, T, Ci, Co, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mask_out = ctx.saved_tensors
+        B, T, Ci, Co, has_bias = ctx.cfg
+        T2 = 2 * T
+        st = _stream()
+        g = torch.empty_like(dy)                                   # d/d(raw) = dy * mask
+        check(lib.avdf_bias_mask_fwd(_p(dy.contiguous()), None, _p(mask_out), _p(g), B * T2, Co, st), "bias_mask_bwd")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.avdf_conv1d_fwd(_p(g), _p(w), None, None, _p(dx), None, B, T2, Co, T, Ci, 3, 2, ACT_NONE, st),
+                  "conv_transpose1d_dx")
+        mw, mb = ctx.main
+        acc = 1 if mw is not None else 0
+        if ctx.needs_input_grad[1]:
+            dw = mw.view(w.shape) if acc else torch.empty_like(w)
+            ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, T, Co, Ci, 3), x)
+            check(lib.avdf_conv1d_bwd_weight(_p(x), _p(g), None, None, _p(dw), None, _p(ws), B, T2, Co, T, Ci, 3, 2,
+                                             ACT_NONE, acc, st), "conv_transpose1d_dw")
+        if has_bias and ctx.needs_input_grad[2]:
+            accb = 1 if mb is not None else 0
+            db = mb.view(Co) if accb else torch.empty(Co, dtype=w.dtype, device=w.device)
+            ws2 = _ws(lib.avdf_masked_colsum_ws(Co), x)
+            check(lib.avdf_masked_colsum(_p(g), None, _p(db), _p(ws2), B * T2, Co, accb, st), "masked_colsum")
+            if accb:
+                db = None
+        if acc:
+            dw = None
+        return dx, dw, db, None
+
+
+def conv_transpose1d_k3s2(x, w, bias, mask_out):
+    return ConvTranspose1dFn.apply(x, w, bias, mask_out)
+
+
+class L1MeanFn(torch.autograd.Function):
+    """mean(|a[sel] - b[sel]|) over the clips with wb == 1 (b is a constant target)."""
+
+    @staticmethod
+    def forward(ctx, a, b, wb, n_sel):
+        a, b, wb = _c(a), _c(b), _c(wb)
+        B = a.shape[0]
+        per = a.numel() // B
+        denom = float(n_sel) * per
+        inv = (1.0 / denom) if denom > 0 else float("nan")          # torch.mean of an empty tensor is nan
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        ws = _ws(lib.avdf_l1_mean_ws(), a)
+        check(lib.avdf_l1_mean(_p(a), _p(b), _p(wb), _p(out), _p(da), _p(ws), B, per, inv, _stream()), "l1_mean")
+        ctx.save_for_backward(da)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (da,) = ctx.saved_tensors
+        return da * g, None, None, None
+
+
+def l1_mean(a, b, wb, n_sel):
+    return L1MeanFn.apply(a, b, wb, n_sel)
+
+
 def linear(x2d, w, bias=None, act=ACT_NONE):
     """nn.Linear on [M, Cin] rows via the K=1 conv path (weight [out, in])."""
     M, Cin = x2d.shape

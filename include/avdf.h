@@ -118,6 +118,11 @@ int avdf_upsample_bwd(const float* dy, float* dx, int B, int Tin, int C, int r, 
 int avdf_downsample_fwd(const float* x, float* y, int B, int Tin, int C, int r, void* stream);
 int avdf_downsample_bwd(const float* dy, float* dx, int B, int Tin, int C, int r, void* stream);
 int avdf_add_upsampled(const float* a, const float* small, float* out, int B, int T, int C, int r, void* stream);
+/* y = (x + bias[c]) * mask[row]: MaskedConvTranspose1D epilogue (blocks.py:1477-1489); its bias gradient */
+int avdf_bias_mask_fwd(const float* x, const float* bias, const float* mask, float* y, int64_t M, int C, void* stream);
+int64_t avdf_masked_colsum_ws(int C);
+int avdf_masked_colsum(const float* dy, const float* mask, float* out, float* ws, int64_t M, int C,
+                       int accumulate, void* stream);
 /* y = x * s (per-row scalar s[M], e.g. dropout keep mask) */
 int avdf_scale_rows(const float* x, const float* s, float* y, int M, int C, void* stream);
 /* layout change at the plugin boundary: [B,C,T] <-> [B,T,C] */
@@ -173,6 +178,11 @@ int avdf_loc_losses(const float* logits, const float* offsets, const float* pmas
                     float* ws_partial, int B, int P, float label_smoothing, float loss_weight,
                     float video_weight, float momentum, void* stream);
 
+/* L1 reconstruction loss of exp5 over the real clips (av_fd_meta_arch.py:683-686): out[0] = inv_denom *
+ * sum_b wb[b] * sum|a-b|; da (optional) = wb[b]*sign(a-b)*inv_denom.  ws: avdf_l1_mean_ws() floats.     */
+int64_t avdf_l1_mean_ws(void);
+int avdf_l1_mean(const float* a, const float* b, const float* wb, float* out, float* da, float* ws,
+                 int B, int64_t per_clip, float inv_denom, void* stream);
 /* sigmoid_focal_loss(x, t, reduction='sum') (losses.py:5-53, alpha .25, gamma 2) over n elements; dx optional.
  * Used for the frame-level loss of exp13 (av_fd_no_recon2.py:718-725).                               */
 int avdf_focal_loss_sum(const float* x, const float* t, float* out, float* dx, int64_t n, void* stream);

@@ -63,7 +63,8 @@ def ref_forward_heads(model, x, mask_f):
     mb = mask_f > 0
     front = model.interpolator if hasattr(model, "interpolator") else model.segmentandCls
     norm_inputs, reco, cls_scores = front(x, mb)
-    feats, masks = model.backbone(x, norm_inputs, x, mb)
+    recon = type(model).__module__.endswith("av_fd_meta_arch")        # exp5: Expansion output feeds the backbone
+    feats, masks = model.backbone(x, norm_inputs, reco if recon else x, mb)
     fpn_feats, fpn_masks = model.neck(feats, masks)
     logits = [t.permute(0, 2, 1) for t in model.cls_head(fpn_feats, fpn_masks)]
     offsets = [t.permute(0, 2, 1) for t in model.reg_head(fpn_feats, fpn_masks)]
@@ -193,9 +194,12 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
     # oracle
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = R.model_forward(sdg, cfg, x, mask, training=True)
-    ol, norm, npos = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], gt_frame_labels=gfl if the else None)
+    ol, norm, npos = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], x_in=x,
+                              gt_frame_labels=gfl if the else None)
     ol["final_loss"].backward()
-    lkeys = ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss") + (("reco_seg_loss",) if the else ())
+    recon = cfg["variant"] == "recon"
+    lkeys = ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss") + (("reco_seg_loss",) if the else ()) + \
+        (("reco_loss",) if recon else ())
     for k in lkeys:
         print(f"[{name}] {k}: ref {float(losses[k]):.6f} oracle {float(ol[k]):.6f}")
         assert abs(float(losses[k]) - float(ol[k])) < 1e-4 * max(1.0, abs(float(losses[k])))
@@ -212,6 +216,11 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
     else:
         gkeys += ["interpolator.contraction.down_3.conv_block.conv.weight", "interpolator.conv1.weight",
                   "interpolator.bn1.bias"]
+    if recon:
+        gkeys += ["interpolator.expansion.up_1.conv_transpose.conv.weight",
+                  "interpolator.expansion.up_3.conv_transpose.conv.bias",
+                  "interpolator.expansion.up_5.conv_transpose.conv.weight",
+                  "backbone.resselfattention.attn.key_conv.conv.weight", "backbone.resselfattention.lnk.weight"]
     named = dict(model.named_parameters())
     store = {}
     worst = 0.0
@@ -234,6 +243,7 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
         is_fake=np.array([g is not None for g in gts]),
         losses=np.array([float(losses[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")]),
         reco_seg_loss=float(losses["reco_seg_loss"]) if the else 0.0,
+        reco_loss=float(losses["reco_loss"]) if recon else 0.0,
         gt_frame_labels=np.array([np.zeros(0, np.float32) if f is None else f.numpy() for f in gfl], dtype=object),
         loss_normalizer=float(model.loss_normalizer), num_dead=len(dead),
         dead_prefixes=np.array(sorted({".".join(d.split(".")[:3]) for d in dead})), **store)
@@ -311,6 +321,8 @@ def main():
     case_forward("fwd_exp10", R.make_cfg(), [768, 700], 21, 22, ctx)
     case_forward("fwd_the_small", R.make_cfg(variant="the", **SMALL), [192, 133], 31, 32, ctx)
     case_train("train_the_small", R.make_cfg(variant="the", **SMALL), [192, 150, 180, 192], 33, 34, ctx)
+    case_forward("fwd_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 140], 41, 42, ctx)
+    case_train("train_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 150, 180, 192], 43, 44, ctx)
     print("done")
 
 

@@ -62,10 +62,12 @@ def maxerr(a, b):
 
 
 THE_SMALL = dict(variant="the", **SMALL)
+RECON_SMALL = dict(variant="recon", **SMALL)
 
 
 @pytest.mark.parametrize("name,over", [("fwd_small", SMALL), ("fwd_small_init", SMALL), ("fwd_mid", MID),
-                                       ("fwd_exp10", {}), ("fwd_the_small", THE_SMALL)])
+                                       ("fwd_exp10", {}), ("fwd_the_small", THE_SMALL),
+                                       ("fwd_recon_small", RECON_SMALL)])
 def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
     model, sd, cfg = build(over, int(g["wseed"]), bool(int(g["trained_like"])))
@@ -103,7 +105,8 @@ def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
-@pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID), ("train_the_small", THE_SMALL)])
+@pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID), ("train_the_small", THE_SMALL),
+                                       ("train_recon_small", RECON_SMALL)])
 def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name, over, accumulate):
     """accumulate=False: deterministic slab reductions, autograd owns the gradients.
     accumulate=True: the engine path -- every backward kernel adds straight into `param.main_grad`
@@ -127,6 +130,8 @@ def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name,
     losses["final_loss"].backward()
     if cfg["variant"] == "the":
         assert abs(float(losses["reco_seg_loss"]) - float(g["reco_seg_loss"])) < 1e-5
+    if cfg["variant"] == "recon":
+        assert abs(float(losses["reco_loss"]) - float(g["reco_loss"])) < 1e-5
     got = np.array([float(losses[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
     print(f"[{name}] losses got {got} ref {g['losses']}")
     assert np.allclose(got, g["losses"], rtol=1e-4, atol=1e-5)
