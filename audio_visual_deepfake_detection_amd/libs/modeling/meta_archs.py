@@ -191,11 +191,22 @@ class AVPtTransformerRecovery(nn.Module):
     def preprocessing(self, video_list, padding_val=0.0):
         """av_fd_no_recon.py:431-479, producing TIME-MAJOR device tensors: x [B, T, C], mask fp32 [B, T].
 
-        Each item carries either the reference's 'feats' ([C, T_i] fp32, CPU or device) or the fast-path
-        'feats_tm' ([T_i, C] fp32 already on the device, e.g. from the K1 interpolation kernel).
+        Each item carries either the reference's 'feats' ([C, T_i] fp32, CPU or device), the fast-path
+        'feats_tm' ([T_i, C] fp32 already on the device), or -- what this package's datasets produce --
+        'streams' (raw per-modality [T_s, C_s] arrays) + 'crop': the K1 kernel resamples every stream to
+        max_seq_len rows and concatenates them on the device (deepfake_video_audio.py:1722-1756), then the
+        random crop of truncate_feats (data_utils.py:124) is a row slice.
         """
         dev = self.device
         assert dev.type == "cuda", "the MI355X path needs the model on a HIP device (no CPU fallback)"
+        if 'streams' in video_list[0]:
+            staged = []
+            for v in video_list:
+                ss = [torch.as_tensor(s, dtype=torch.float32).to(dev, non_blocking=True) for s in v['streams']]
+                full = ops.interp_concat(ss, self.max_seq_len)
+                st, ed = v['crop'] if v.get('crop') is not None else (0, self.max_seq_len)
+                staged.append(dict(v, feats_tm=full[st:ed]))
+            video_list = staged
         tm = 'feats_tm' in video_list[0]
         lens = [int(v['feats_tm'].shape[0] if tm else v['feats'].shape[-1]) for v in video_list]
         max_len = max(lens)

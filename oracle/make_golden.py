@@ -303,6 +303,48 @@ def case_interp():
     print("[interp] stored 4 cases + known answer")
 
 
+def case_datasets():
+    """Reference dataset classes on a synthetic tree (oracle/synth_data.py): per-item metadata, segments after
+    the seeded random crop, and checksums of the interpolated+concatenated+cropped feature matrix."""
+    import random
+    import tempfile
+    from oracle.synth_data import make_synth_tree, dataset_kwargs
+    from libs.datasets import make_dataset, make_inference_dataset
+    root = tempfile.mkdtemp(prefix="avdf_synth_")
+    rels = make_synth_tree(root, seed=0)
+    kw = dataset_kwargs(root)
+    out = {"n": len(rels)}
+    for tag, name in (("a", "deepfake_video_audioEmoBYOLA"), ("t", "deepfake_video_audioEmoBYOLA_THE")):
+        ds = make_dataset(name, True, ["train"], **kw)
+        for i in range(len(ds)):
+            random.seed(100 + i)
+            d = ds[i]
+            f = d["feats"]
+            out[f"{tag}{i}_shape"] = np.array(f.shape)
+            out[f"{tag}{i}_sum"] = np.array([float(f.double().sum()), float(f.double().abs().sum())])
+            out[f"{tag}{i}_col0"] = f[:, 0].numpy()
+            out[f"{tag}{i}_colN"] = f[:, -1].numpy()
+            out[f"{tag}{i}_segments"] = np.zeros((0, 2), np.float32) if d["segments"] is None else d["segments"].numpy()
+            out[f"{tag}{i}_meta"] = np.array([d["fps"], d["duration"], d["feat_stride"], d["feat_num_frames"]], np.float64)
+            out[f"{tag}{i}_av"] = d["av_labels"].numpy()
+            if tag == "t":
+                gl = d["gt_frame_labels"]
+                out[f"{tag}{i}_frames"] = np.zeros(0, np.float32) if gl is None else gl.numpy()
+    kwi = dict(crop_ratio=kw["crop_ratio"], default_fps=None, downsample_rate=0, video_feat_folder=kw["video_feat_folder"],
+               audio_feat_folder=None, audio_byola_feat_folder=kw["audio_byola_feat_folder"],
+               audio_emo_feat_folder=kw["audio_emo_feat_folder"], audio_file_ext=".npy", num_classes=1, input_dim=0,
+               video_input_dim=8, audio_input_dim=24, feat_stride=1, num_frames=1,
+               test_folder=os.path.join(root, "test_folder"), trunc_thresh=0.5, max_seq_len=768, force_upsampling=True)
+    dsi = make_inference_dataset("deepfake_video_audioEmoBYOLA_inference", False, ["test"], 1, **kwi)
+    for i in range(len(dsi)):
+        d = dsi[i]
+        f = d["feats"]
+        out[f"i{i}_sum"] = np.array([float(f.double().sum()), float(f.double().abs().sum())])
+        out[f"i{i}_meta"] = np.array([d["fps"], d["duration"], d["feat_stride"], d["feat_num_frames"]], np.float64)
+    np.savez_compressed(os.path.join(GOLD, "datasets.npz"), **out)
+    print("[datasets] stored", len(rels), "items x 3 dataset classes")
+
+
 SMALL = dict(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, head_dim=32)
 MID = dict(input_dim=192, max_seq_len=384, embd_dim=128, n_head=4, fpn_dim=128, head_dim=128)
 
@@ -313,6 +355,7 @@ def main():
     ctx = import_reference()
     case_interp()
     case_nms()
+    case_datasets()
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
     case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
     case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)

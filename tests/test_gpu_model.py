@@ -201,3 +201,36 @@ def test_cpu_tensors_fail_loudly():
     from audio_visual_deepfake_detection_amd import ops
     with pytest.raises(RuntimeError):
         ops.layernorm(torch.zeros(2, 4, 8), torch.ones(1, 8, 1), torch.zeros(1, 8, 1))
+
+
+def test_dataset_items_through_model(tmp_path):
+    """Items of this package's dataset plugin (raw streams + crop window) through the model: the on-device K1
+    interpolation + crop + padding must equal the CPU interpolation of the reference's dataset, and the
+    training / eval entry points must accept the items unchanged."""
+    import random
+    from audio_visual_deepfake_detection_amd import build_model
+    from audio_visual_deepfake_detection_amd.libs.datasets import make_dataset, make_data_loader
+    from oracle import ummaformer_ref as R
+    from oracle.synth_data import make_synth_tree, dataset_kwargs
+    root = str(tmp_path)
+    make_synth_tree(root, seed=3, n=4)
+    ds = make_dataset("deepfake_video_audioEmoBYOLA", True, ["train"], **dataset_kwargs(root))
+    model, _ = build_model("deepfake_exp10.yaml", video_input_dim=8, audio_input_dim=24, embd_dim=32, fpn_dim=32,
+                           head_dim=32)
+    model = model.to("cuda:0").train()
+    random.seed(5)
+    batch = [ds[i] for i in range(4)]
+    x, mask = model.preprocessing(batch)
+    for b, it in enumerate(batch):
+        ref = R.interp_concat(it["streams"], 768)
+        st, ed = it["crop"] if it["crop"] is not None else (0, 768)
+        ref = ref[:, st:ed].t()
+        n = ref.shape[0]
+        assert torch.equal(x[b, :n].cpu(), ref), f"clip {b}: device K1+crop differs from the CPU interpolation"
+        assert float(x[b, n:].abs().sum()) == 0.0 and float(mask[b].sum()) == n
+    losses = model(batch)
+    losses["final_loss"].backward()
+    assert torch.isfinite(losses["final_loss"]).item()
+    model.eval()
+    res = model([batch[0]])[0]
+    assert res["segments"].shape[1] == 2 and res["video_id"] == batch[0]["video_id"]
