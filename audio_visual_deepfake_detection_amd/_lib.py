@@ -69,6 +69,7 @@ SIGNATURES = {
     "avdf_conv2d_c1_bn_relu_pool": (I, [P, P, P, P, P, I, I, I, P]),
     "avdf_mel_im2col": (I, [P, P, I, I, I, P]),
     "avdf_maxpool2x2": (I, [P, P, I, I, I, I, P]),
+    "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
     "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),

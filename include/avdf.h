@@ -218,6 +218,11 @@ int avdf_conv2d_c1_bn_relu_pool(const float* x /*[M,T]*/, const float* w /*[C,9]
 int avdf_mel_im2col(const float* x /*[M,T,C]*/, float* xcol /*[M,T,3C]*/, int M, int T, int C, void* stream);
 int avdf_maxpool2x2(const float* x /*[M,T,C]*/, float* out, int M, int T, int C, int t_major, void* stream);
 
+/* host mirror of batched_nms (class-agnostic hard branch) + seg_voting (libs/utils/nms.py:67-190); HOST pointers */
+int avdf_batched_nms_host(const float* segs, const float* scores, int64_t n, float iou_thr, float min_score,
+                          int64_t max_seg, float voting_thr, float* out_segs, float* out_scores,
+                          int64_t* out_idx, int64_t* n_out);
+
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);
 int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);

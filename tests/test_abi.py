@@ -72,3 +72,23 @@ def test_host_nms_matches_reference_vectors(golden_dir):
         # implementation-defined, so compare the kept set and the descending score sequence
         assert sorted(got.tolist()) == sorted(ref.tolist()), i
         assert np.array_equal(sc[got], sc[ref]), i
+
+
+def test_batched_nms_api_matches_reference_outputs(golden_dir):
+    """libs.utils.batched_nms (reference API) vs the reference's own outputs incl. voting, two min_score settings."""
+    import numpy as np
+    import torch
+    from audio_visual_deepfake_detection_amd.libs.utils import batched_nms
+    g = np.load(os.path.join(golden_dir, "nms.npz"))
+    for i in range(int(g["n_cases"])):
+        segs, sc = torch.from_numpy(g[f"segs{i}"]).reshape(-1, 2), torch.from_numpy(g[f"scores{i}"])
+        for tag, ms in (("a", 0.001), ("b", 0.2)):
+            s, c, l = batched_nms(segs, sc, torch.zeros(sc.shape[0], dtype=torch.int64), 0.1, ms, 100,
+                                  use_soft_nms=False, multiclass=False, sigma=0.75, voting_thresh=0.9)
+            rs, rc = g[f"bn_segs{i}{tag}"], g[f"bn_scores{i}{tag}"]
+            assert s.shape[0] == rs.shape[0], (i, tag)
+            assert np.array_equal(np.sort(c.numpy())[::-1], np.sort(rc)[::-1])
+            # order-insensitive among exact score ties (the reference sort is unstable)
+            o1 = np.lexsort((s.numpy()[:, 0], -c.numpy()))
+            o2 = np.lexsort((rs[:, 0], -rc))
+            assert np.allclose(s.numpy()[o1], rs[o2], atol=1e-3), (i, tag)
