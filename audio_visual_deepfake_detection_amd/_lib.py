@@ -17,6 +17,7 @@ SIGNATURES = {
     "avdf_last_error": (ctypes.c_char_p, []),
     "avdf_version": (I, []),
     "avdf_conv1d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "avdf_conv1d_fwd_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_weight_ws": (L, [I, I, I, I, I]),
     "avdf_conv1d_bwd_weight": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
@@ -70,6 +71,9 @@ SIGNATURES = {
     "avdf_mel_im2col": (I, [P, P, I, I, I, P]),
     "avdf_maxpool2x2": (I, [P, P, I, I, I, I, P]),
     "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
+    "avdf_wave_conv_c1": (I, [P, P, P, L, L, I, I, I, P]),
+    "avdf_grouped_conv_pos": (I, [P, P, P, P, I, I, I, I, P]),
+    "avdf_softmax_alibi": (I, [P, I, I, F, F, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
     "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),

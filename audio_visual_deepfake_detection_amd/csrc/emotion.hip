@@ -1,0 +1,134 @@
+// Emotion2Vec (data2vec 2.0 audio) encoder glue -- frozen extractor, forward only.
+// Reference: audio_feature/emotion_audio/upstream/models/{emotion2vec.py:97-188, audio.py:52-138,
+// base.py:189-329,538-642, modules.py:184-322} plus fairseq's ConvFeatureExtractionModel (named at audio.py:12-17).
+// The 512-channel strided convs, every Linear, Q.K^T and P.V run on the fp32 MFMA GEMM (gemm_conv.hip,
+// avdf_conv1d_fwd_ex); this file holds what is not GEMM-shaped:
+//   * first feature-extractor layer (1 input channel, k=10, stride 5),
+//   * grouped positional conv (768 ch, 16 groups, k=19, "same" padding),
+//   * softmax with the symmetric ALiBi bias  -slope_h * |i - j| * scale  (base.py:538-642).
+// Layout: tokens time-major [T, C]; attention scores [Tq, ld] per head.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// y[t, n] = sum_k pcm[t*S + k] * w[n, k]   (Cin = 1, no padding, no bias)
+__global__ __launch_bounds__(256) void wave_conv_c1_kernel(const float* __restrict__ pcm, const float* __restrict__ w,
+                                                           float* __restrict__ y, long T, int C, int K, int S) {
+  const int C4 = C >> 2;
+  const long total = T * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i % C4) * 4;
+    const long t = i / C4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      const float xv = pcm[t * S + k];
+      acc.x += xv * w[(n + 0) * K + k]; acc.y += xv * w[(n + 1) * K + k];
+      acc.z += xv * w[(n + 2) * K + k]; acc.w += xv * w[(n + 3) * K + k];
+    }
+    st4(y + t * C + n, acc);
+  }
+}
+
+// y[t, g*CG + co] = bias + sum_{ci<CG, k<K} x[t + k - K/2, g*CG + ci] * w[g*CG + co, ci, k]
+// one workgroup = (32-token tile, group); threads = CG output channels x 256/CG token lanes; x tile in LDS
+template <int CG, int K>
+__global__ __launch_bounds__(256) void grouped_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int T, int C, int tiles) {
+  constexpr int TT = 32, P = K / 2, R = TT + K - 1;
+  constexpr int LANES = 256 / CG;                 // token lanes per output channel
+  constexpr int PER = (TT + LANES - 1) / LANES;   // tokens per thread
+  __shared__ float xs[R][CG + 1];
+  const int g = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TT;
+  for (int i = threadIdx.x; i < R * CG; i += 256) {
+    const int r = i / CG, ci = i % CG;
+    const int t = t0 - P + r;
+    xs[r][ci] = (t >= 0 && t < T) ? x[(size_t)t * C + g * CG + ci] : 0.f;
+  }
+  __syncthreads();
+  const int co = threadIdx.x % CG, tl = threadIdx.x / CG;
+  if (tl >= LANES) return;
+  float acc[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) acc[q] = bias ? bias[g * CG + co] : 0.f;
+  const float* wr = w + (size_t)(g * CG + co) * CG * K;
+  for (int ci = 0; ci < CG; ++ci) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float wv = wr[ci * K + k];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int tt = tl + q * LANES;
+        if (tt < TT) acc[q] += wv * xs[tt + k][ci];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int t = t0 + tl + q * LANES;
+    if (tl + q * LANES < TT && t < T) y[(size_t)t * C + g * CG + co] = acc[q];
+  }
+}
+
+// in place: P[i, j] = softmax_j( S[i, j]*qk_scale - slope * |i - j| ) for j < T, 0 for T <= j < ld.  One wave per row.
+__global__ __launch_bounds__(256) void softmax_alibi_kernel(float* __restrict__ s, int T, int ld, float qk_scale, float slope) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= T) return;
+  float* row = s + (size_t)i * ld;
+  float m = -INFINITY;
+  for (int j = lane; j < T; j += 64) {
+    const float v = row[j] * qk_scale - slope * fabsf((float)(i - j));
+    row[j] = v;
+    m = fmaxf(m, v);
+  }
+  m = wave_max(m);
+  float den = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float e = __expf(row[j] - m);
+    row[j] = e;
+    den += e;
+  }
+  den = wave_sum(den);
+  const float inv = 1.0f / den;
+  for (int j = lane; j < ld; j += 64) row[j] = j < T ? row[j] * inv : 0.f;
+}
+
+inline int grid_for(long total) {
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int avdf_wave_conv_c1(const float* pcm, const float* w, float* y, int64_t n_samples, int64_t Tout, int C,
+                                 int K, int stride, void* stream) {
+  AVDF_REQUIRE(pcm && w && y && Tout > 0 && C > 0 && C % 4 == 0 && K > 0 && stride > 0, "wave_conv_c1: bad args");
+  AVDF_REQUIRE((Tout - 1) * stride + K <= n_samples, "wave_conv_c1: Tout exceeds the valid-conv length");
+  hipLaunchKernelGGL(wave_conv_c1_kernel, dim3(grid_for(Tout * C / 4)), dim3(256), 0, (hipStream_t)stream, pcm, w, y,
+                     (long)Tout, C, K, stride);
+  AVDF_CHECK_LAUNCH("wave_conv_c1");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, float* y, int T, int C,
+                                     int groups, int K, void* stream) {
+  AVDF_REQUIRE(x && w && y && T > 0 && C > 0 && groups > 0 && C % groups == 0, "grouped_conv_pos: bad args");
+  AVDF_REQUIRE(C / groups == 48 && K == 19, "grouped_conv_pos: only 48 channels/group, k=19 (emotion2vec conv_pos) is built");
+  const int tiles = cdiv(T, 32);
+  hipLaunchKernelGGL((grouped_conv_kernel<48, 19>), dim3(groups * tiles), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, T, C, tiles);
+  AVDF_CHECK_LAUNCH("grouped_conv_pos");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream) {
+  AVDF_REQUIRE(scores && T > 0 && ld >= T, "softmax_alibi: bad args");
+  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, scores, T, ld, qk_scale, slope);
+  AVDF_CHECK_LAUNCH("softmax_alibi");
+  return AVDF_OK;
+}

@@ -84,11 +84,13 @@ template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
 __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ ypre,
-    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
+    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy) {
+  // P = left zero-padding (K/2 for the "same" convs of the model, 0 for the wav2vec2 feature extractor);
+  // ldx / ldw / ldy = row strides of x, w and y in floats (sub-matrix views: attention heads, weight slices)
   static_assert(WM * WN == 4, "4 waves per K-group");
   static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
   constexpr int NT = 256 * KG;
-  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int RA = (BM - 1) * S + KS;
   constexpr int LDA = KC + 1;
   constexpr int KB = KC * KS;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       if (q < RA * A4) {
         const int row = q / A4, c = c0 + (q % A4) * 4;
         const int tr = t0 * S - P + row;
-        if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + tr) * Cin + c);
+        if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + tr) * ldx + c);
       }
       ra.v[i] = v;
     }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       float4 v = zero4();
       if (q < BN * B4) {
         const int n = n0 + q / B4, e = c0 * KS + (q % B4) * 4;
-        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * Cin * KS + e);
+        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * ldw + e);
       }
       rb.v[i] = v;
     }
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
         if (t >= Tout) continue;
         const size_t row = (size_t)b * Tout + t;
         float v = acc[mi * NI + ni][r] + bn;
-        if (ypre) ypre[row * Cout + n] = v;
+        if (ypre) ypre[row * ldy + n] = v;
         v = act_f(v, act);
         if (mask) v *= mask[row];
-        y[row * Cout + n] = v;
+        y[row * ldy + n] = v;
       }
     }
   }
@@ -662,6 +664,28 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
     default: L(KS_, S_, KC3_, 1, 4, 1, 1, 4); break;                               \
   }
 
+static int conv1d_fwd_launch(const float* x, const float* w, const float* bias, const float* mask, float* y,
+                             float* ypre, int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int pad,
+                             int ldx, int ldw, int ldy, int act, hipStream_t st) {
+  const TilePlan plan = pick_tile(B, Tout, Cout);
+#define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
+  do {                                                                                                  \
+    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
+    const int tilesT = cdiv(Tout, BM_);                                                                 \
+    dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                             \
+    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
+                       0, st, x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
+                       ldx, ldw, ldy);                                                                  \
+  } while (0)
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_FWD) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_FWD) }
+  else if (K == 2 && stride == 2) { AVDF_GEMM_DISPATCH(2, 2, 64, 64, 64, 64, LAUNCH_FWD) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, LAUNCH_FWD) }
+#undef LAUNCH_FWD
+  AVDF_CHECK_LAUNCH("conv1d_fwd");
+  return AVDF_OK;
+}
+
 extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const float* mask,
                                float* y, float* ypre, int B, int Tin, int Cin, int Tout, int Cout,
                                int K, int stride, int act, void* stream) {
@@ -672,22 +696,27 @@ extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias
   AVDF_REQUIRE(Cin % 4 == 0, "conv1d_fwd: Cin %% 4 != 0 (Cin=%d)", Cin);
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd: Tout=%d inconsistent with Tin=%d K=%d s=%d", Tout, Tin, K, stride);
   AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd: x/w must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  const TilePlan plan = pick_tile(B, Tout, Cout);
-#define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
-  do {                                                                                                  \
-    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
-    const int tilesT = cdiv(Tout, BM_);                                                                 \
-    dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                             \
-    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
-                       0, st, x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT);         \
-  } while (0)
-  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_FWD) }
-  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_FWD) }
-  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, LAUNCH_FWD) }
-#undef LAUNCH_FWD
-  AVDF_CHECK_LAUNCH("conv1d_fwd");
-  return AVDF_OK;
+  return conv1d_fwd_launch(x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin, Cin * K, Cout,
+                           act, (hipStream_t)stream);
+}
+
+// General forward form used by the frozen extractors: explicit zero-padding `pad` (0 = "valid" conv of the
+// wav2vec2 feature extractor, fairseq ConvFeatureExtractionModel) and explicit row strides, so x / w / y may be
+// column slices of wider matrices (attention heads: Q_h.K_h^T and P.V_h^T without copies).
+// (K, stride) in {(1,1), (2,2), (3,1), (3,2)}; Cin, ldx, ldw multiples of 4.
+extern "C" int avdf_conv1d_fwd_ex(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Cin,
+                                  int Tout, int Cout, int K, int stride, int pad, int ldx, int ldw, int ldy, int act,
+                                  void* stream) {
+  AVDF_REQUIRE(x && w && y, "conv1d_fwd_ex: null pointer");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0 && pad >= 0, "conv1d_fwd_ex: bad dims");
+  AVDF_REQUIRE((K == 1 && stride == 1) || (K == 2 && stride == 2) || (K == 3 && (stride == 1 || stride == 2)),
+               "conv1d_fwd_ex: unsupported (K=%d, stride=%d)", K, stride);
+  AVDF_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ldx >= Cin && ldw >= Cin * K && ldy >= Cout,
+               "conv1d_fwd_ex: Cin/ldx/ldw must be multiples of 4 and cover the operands");
+  AVDF_REQUIRE(Tout == (Tin + 2 * pad - K) / stride + 1, "conv1d_fwd_ex: Tout=%d inconsistent", Tout);
+  AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd_ex: x/w must be 16-byte aligned");
+  return conv1d_fwd_launch(x, w, bias, nullptr, y, nullptr, B, Tin, Cin, Tout, Cout, K, stride, pad, ldx, ldw, ldy,
+                           act, (hipStream_t)stream);
 }
 
 extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
       o.y = (v[j].y - mean) * rstd * g.y + bb.y;
       o.z = (v[j].z - mean) * rstd * g.z + bb.z;
       o.w = (v[j].w - mean) * rstd * g.w + bb.w;
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (relu == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      else if (relu == 2) { o.x = gelu_f(o.x); o.y = gelu_f(o.y); o.z = gelu_f(o.z); o.w = gelu_f(o.w); }   // fused GELU (extractors)
       if (pe) {
         const float4 p = ld4(pe + (size_t)t * C + c);
         o.x += p.x * mk; o.y += p.y * mk; o.z += p.z * mk; o.w += p.w * mk;
@@ -258,6 +259,7 @@ extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* 
                                   const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
                                   float* ws, int M, int C, int relu, int accumulate, void* stream) {
   AVDF_REQUIRE(dy && x && mean && rstd && dx && ws && M > 0 && C > 0, "layernorm_bwd: bad args");
+  AVDF_REQUIRE(relu == 0 || relu == 1, "layernorm_bwd: only the none / ReLU epilogues have a backward");
   AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "layernorm_bwd: C must be a multiple of 4 and <= %d", 256 * kLnMaxV);
   AVDF_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm_bwd: gamma/beta");
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && (!gamma || (aligned16(gamma) && aligned16(beta))), "layernorm_bwd: 16-byte alignment");

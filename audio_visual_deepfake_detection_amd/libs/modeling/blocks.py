@@ -167,16 +167,33 @@ class _MHCABase(nn.Module):
         self.value = nn.Conv1d(n_embd, n_embd, 1)
         self.proj = nn.Conv1d(n_embd, n_embd, 1)
 
+    def _branch(self, conv, norm, proj, x, mask):
+        y, out_mask = conv(x, mask)
+        return ops.conv1d(norm(y), proj.weight, proj.bias), out_mask
+
     def _attend(self, x_q, mask_q, x_k, mask_k, x_v, mask_v):
-        q, qx_mask = self.query_conv(x_q, mask_q)
-        q = self.query_norm(q)
-        k, kv_mask = self.key_conv(x_k, mask_k)
-        k = self.key_norm(k)
-        v, _ = self.value_conv(x_v, mask_v)
-        v = self.value_norm(v)
-        q = ops.conv1d(q, self.query.weight, self.query.bias)
-        k = ops.conv1d(k, self.key.weight, self.key.bias)
-        v = ops.conv1d(v, self.value.weight, self.value.bias)
+        if ops.BRANCH_STREAMS and x_q.is_cuda:
+            # the q / k / v chains (depthwise conv -> LayerNorm -> 1x1 projection) are independent and each is
+            # far too small to fill 256 CUs: run them on three HIP streams (fork / join); autograd replays the
+            # same streams in the backward pass and a captured hipGraph keeps the parallel branches
+            cur = torch.cuda.current_stream()
+            s1, s2 = ops.side_streams(x_q.device)
+            s1.wait_stream(cur)
+            s2.wait_stream(cur)
+            q, qx_mask = self._branch(self.query_conv, self.query_norm, self.query, x_q, mask_q)
+            with torch.cuda.stream(s1):
+                k, kv_mask = self._branch(self.key_conv, self.key_norm, self.key, x_k, mask_k)
+            with torch.cuda.stream(s2):
+                v, _ = self._branch(self.value_conv, self.value_norm, self.value, x_v, mask_v)
+            cur.wait_stream(s1)
+            cur.wait_stream(s2)
+            k.record_stream(cur)
+            v.record_stream(cur)
+            kv_mask.record_stream(cur)
+        else:
+            q, qx_mask = self._branch(self.query_conv, self.query_norm, self.query, x_q, mask_q)
+            k, kv_mask = self._branch(self.key_conv, self.key_norm, self.key, x_k, mask_k)
+            v, _ = self._branch(self.value_conv, self.value_norm, self.value, x_v, mask_v)
         if self.window_size > 1:
             out = ops.local_attention(q, k, v, kv_mask, self.n_head, self.window_size)
         else:

@@ -13,6 +13,18 @@ from ._lib import lib, check
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
+# fork/join of independent branches on side streams (blocks._MHCABase._attend); off by default
+BRANCH_STREAMS = False
+_side = {}
+
+
+def side_streams(device):
+    key = str(device)
+    if key not in _side:
+        _side[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _side[key]
+
+
 # optional per-launch timing of the MFMA conv kernels (bench.py roofline pass): list of
 # (kernel tag, algorithmic FLOPs, start event, end event) recorded on the launch stream
 _prof = None

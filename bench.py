@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--branch-streams", action="store_true", help="run the q/k/v chains on three HIP streams")
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     args = ap.parse_args()
 
@@ -121,6 +122,7 @@ def main():
     from audio_visual_deepfake_detection_amd import ops
     from audio_visual_deepfake_detection_amd.engine import TrainStep, InferStep
 
+    ops.BRANCH_STREAMS = args.branch_streams
     torch.manual_seed(0)                       # identical random-init weights on every rank
     model, cfg = build_model("deepfake_exp10.yaml")
     model = model.to(dev)

@@ -42,6 +42,15 @@ int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const flo
                     float* y, float* ypre, int B, int Tin, int Cin, int Tout, int Cout,
                     int K, int stride, int act, void* stream);
 
+/* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the
+ * wav2vec2 feature extractor, fairseq ConvFeatureExtractionModel named at audio_feature/emotion_audio/upstream/
+ * models/audio.py:12-17,66-71) and explicit row strides (floats), so x / w / y may be column slices of wider
+ * matrices -- attention heads Q_h.K_h^T and P.V_h^T (modules.py:303-316) without copies.
+ * (K, stride) in {(1,1),(2,2),(3,1),(3,2)}; Cin, ldx, ldw multiples of 4.                                  */
+int avdf_conv1d_fwd_ex(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Cin,
+                       int Tout, int Cout, int K, int stride, int pad, int ldx, int ldw, int ldy, int act,
+                       void* stream);
+
 /* dx[b,t',c] = sum_k sum_n g[b,t,n] * w[n,c,k],  t*stride + k - K/2 == t',
  * with g = dy * mask[b,t] * act'(ypre) (mask / ypre optional).  Cout % 4 == 0 required.      */
 int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,
@@ -222,6 +231,17 @@ int avdf_maxpool2x2(const float* x /*[M,T,C]*/, float* out, int M, int T, int C,
 int avdf_batched_nms_host(const float* segs, const float* scores, int64_t n, float iou_thr, float min_score,
                           int64_t max_seg, float voting_thr, float* out_segs, float* out_scores,
                           int64_t* out_idx, int64_t* n_out);
+
+/* ---- Emotion2Vec (data2vec 2.0 audio) encoder glue, forward only -----------------------------------
+ * first feature-extractor layer (Cin=1, k=10, s=5: audio.py:25-28), grouped positional conv (768 ch, 16 groups,
+ * k=19, same padding: audio.py:79-102) and the in-place softmax with the symmetric ALiBi bias
+ * softmax_j(S*qk_scale - slope*|i-j|) (base.py:538-642; modules.py:303-316).  scores: [T, ld] per head,
+ * columns >= T are zeroed.                                                                             */
+int avdf_wave_conv_c1(const float* pcm, const float* w, float* y, int64_t n_samples, int64_t Tout, int C,
+                      int K, int stride, void* stream);
+int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, float* y, int T, int C,
+                          int groups, int K, void* stream);
+int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream);
 
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);

@@ -1,0 +1,31 @@
+"""CPU checks of the frozen-extractor hosts: checkpoint key layout + output-length rules (no compute on HIP)."""
+import torch
+
+from audio_visual_deepfake_detection_amd.extractors import Emotion2Vec
+from oracle import emotion2vec_ref as R
+
+
+def test_emotion2vec_state_dict_uses_fairseq_keys():
+    m = Emotion2Vec()
+    keys = set(m.state_dict().keys())
+    a = "modality_encoders.AUDIO."
+    for k in [a + "local_encoder.conv_layers.0.0.weight", a + "local_encoder.conv_layers.6.2.1.bias",
+              a + "project_features.1.weight", a + "project_features.2.bias",
+              a + "relative_positional_encoder.1.0.weight", a + "relative_positional_encoder.5.0.bias",
+              a + "context_encoder.blocks.3.attn.qkv.weight", a + "context_encoder.norm.weight", a + "alibi_scale",
+              "blocks.7.mlp.fc2.bias", "blocks.0.norm1.weight"]:
+        assert k in keys, k
+    sd = m.state_dict()
+    assert sd[a + "local_encoder.conv_layers.0.0.weight"].shape == (512, 1, 10)
+    assert sd[a + "local_encoder.conv_layers.5.0.weight"].shape == (512, 512, 2)
+    assert sd[a + "relative_positional_encoder.1.0.weight"].shape == (768, 48, 19)
+    assert sd[a + "alibi_scale"].shape == (12, 1, 12, 1, 1)
+    assert not any("relative_positional_encoder" in k and ".3." in k for k in keys)      # LN without affine
+
+
+def test_emotion2vec_restatement_length_rule_and_alibi_slopes():
+    m = Emotion2Vec(depth=1, prenet_depth=1)
+    y = R.forward(dict(m.state_dict()), torch.randn(1, 4000) * 0.1, prenet_depth=1, depth=1)
+    assert y.shape == (1, (4000 - 400) // 320 + 1, 768)
+    s = R.slopes(12)
+    assert len(s) == 12 and abs(s[0] - 2 ** -1) < 1e-12 and abs(s[7] - 2 ** -8) < 1e-12 and abs(s[8] - 2 ** -0.5) < 1e-12
