@@ -20,7 +20,8 @@ def test_emotion2vec_state_dict_uses_fairseq_keys():
     assert sd[a + "local_encoder.conv_layers.5.0.weight"].shape == (512, 512, 2)
     assert sd[a + "relative_positional_encoder.1.0.weight"].shape == (768, 48, 19)
     assert sd[a + "alibi_scale"].shape == (12, 1, 12, 1, 1)
-    assert not any("relative_positional_encoder" in k and ".3." in k for k in keys)      # LN without affine
+    import re
+    assert not any(re.search(r"relative_positional_encoder\.\d\.3\.", k) for k in keys)      # LN without affine
 
 
 def test_emotion2vec_restatement_length_rule_and_alibi_slopes():
