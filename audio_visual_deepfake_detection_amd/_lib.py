@@ -73,6 +73,9 @@ SIGNATURES = {
     "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
     "avdf_wave_conv_c1": (I, [P, P, P, L, L, I, I, I, P]),
     "avdf_grouped_conv_pos": (I, [P, P, P, P, I, I, I, I, P]),
+    "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "avdf_video_prep": (I, [P, P, I, I, I, I, I, P]),
+    "avdf_maxpool_hw": (I, [P, P, L, I, I, I, I, P]),
     "avdf_softmax_alibi": (I, [P, I, I, F, F, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),

@@ -51,11 +51,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __device__ __forceinline__ float act_f(float x, int act) {
   if (act == AVDF_ACT_RELU) return fmaxf(x, 0.0f);
   if (act == AVDF_ACT_GELU) return gelu_f(x);
+  if (act == AVDF_ACT_LEAKY) return x > 0.0f ? x : 0.01f * x;
   return x;
 }
 __device__ __forceinline__ float act_grad_f(float pre, int act) {
   if (act == AVDF_ACT_RELU) return pre > 0.0f ? 1.0f : 0.0f;
   if (act == AVDF_ACT_GELU) return gelu_grad_f(pre);
+  if (act == AVDF_ACT_LEAKY) return pre > 0.0f ? 1.0f : 0.01f;
   return 1.0f;
 }
 

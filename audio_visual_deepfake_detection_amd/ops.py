@@ -11,7 +11,7 @@ import torch
 
 from ._lib import lib, check
 
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_LEAKY = 0, 1, 2, 3
 
 # fork/join of independent branches on side streams (blocks._MHCABase._attend); off by default
 BRANCH_STREAMS = False

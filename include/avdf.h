@@ -27,6 +27,7 @@ extern "C" {
 #define AVDF_ACT_NONE 0
 #define AVDF_ACT_RELU 1
 #define AVDF_ACT_GELU 2   /* exact erf GELU (nn.GELU default) */
+#define AVDF_ACT_LEAKY 3  /* LeakyReLU(0.01) (nn.LeakyReLU default; LAV-DF visual encoder) */
 
 const char* avdf_last_error(void);
 int avdf_version(void);
@@ -242,6 +243,18 @@ int avdf_wave_conv_c1(const float* pcm, const float* w, float* y, int64_t n_samp
 int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, float* y, int T, int C,
                           int groups, int K, void* stream);
 int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream);
+
+/* ---- LAV-DF visual encoder (C3D; frozen extractor, forward only) -------------------------------------
+ * Reference: video_feature/aligned_video/model/video_encoder.py:27-62 (7x Conv3d 3x3x3 pad 1 + LeakyReLU,
+ * MaxPool3d((1,p,p))) and extract_video_features.py:19-37 (/255, tail zero pad, nearest resize to 96x96).
+ * Activations are voxel-major [B, T, H, W, C]; weights tap-major wp[27][Cout][Cin] (tap = (dt*3+dh)*3+dw,
+ * packed once from the reference [Cout, Cin, 3, 3, 3]).                                                  */
+int avdf_conv3d_k3(const float* x, const float* wp, const float* bias, float* y, int B, int T, int H, int W,
+                   int Cin, int Cout, int act, void* stream);
+/* uint8 frames [T, H0, W0, 3] -> fp32 [Tp, S, S, 4] (/255, nearest resize, 4th channel and frames >= T zero) */
+int avdf_video_prep(const uint8_t* frames, float* out, int T, int H0, int W0, int Tp, int S, void* stream);
+/* [N, H, W, C] -> [N, H/p, W/p, C] max over p x p windows (floor mode) */
+int avdf_maxpool_hw(const float* x, float* y, int64_t N, int H, int W, int C, int p, void* stream);
 
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);

@@ -97,3 +97,99 @@ def test_emotion2vec_matches_torch_restatement(n, per_layer):
     assert rel < 1e-3
     trimmed = emotion2vec_features(pcm.to("cuda:0"), md)
     assert trimmed.shape[0] == int(50 * (n / 16000.0) - 0.817)
+
+
+def _c3d_model(batch_norm=False, feats=(64, 96, 128, 128)):
+    from audio_visual_deepfake_detection_amd.extractors import C3DVideoEncoder
+    torch.manual_seed(11)
+    m = C3DVideoEncoder(n_features=feats, batch_norm=batch_norm)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if ".bn." in name:
+                p.normal_(1.0 if name.endswith("weight") else 0.0, 0.1)
+        for name, b in m.named_buffers():
+            if name.endswith("running_mean"):
+                b.normal_(0.0, 0.1)
+            elif name.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+    return m
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W", [(4, 64, 3, 16, 40), (64, 96, 2, 32, 32), (96, 128, 3, 16, 16),
+                                            (128, 128, 5, 8, 8), (128, 128, 6, 4, 4), (64, 64, 2, 19, 35),
+                                            (8, 32, 3, 5, 7)])
+def test_conv3d_k3_matches_torch(cin, cout, T, H, W):
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    g = torch.Generator().manual_seed(cin * 1000 + cout + H)
+    B = 2
+    x = torch.randn(B, cin, T, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(x.double(), w.double(), b.double(), padding=1), 0.01)
+    xd = x.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    wp = w.permute(2, 3, 4, 0, 1).contiguous().cuda()
+    y = torch.empty(B, T, H, W, cout, device="cuda")
+    check(lib.avdf_conv3d_k3(xd.data_ptr(), wp.data_ptr(), b.cuda().data_ptr(), y.data_ptr(), B, T, H, W, cin, cout, 3,
+                             torch.cuda.current_stream().cuda_stream), "conv3d")
+    got = y.permute(0, 4, 1, 2, 3).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"conv3d {cin}->{cout} {T}x{H}x{W}: rel err {err:.2e}")
+    assert err < 2e-6
+
+
+def test_video_prep_and_pool_bit_exact():
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    from oracle import c3d_ref as R
+    g = torch.Generator().manual_seed(5)
+    fr = torch.randint(0, 256, (5, 224, 200, 3), generator=g, dtype=torch.uint8)
+    ref = R.prepare_chunks(fr, chunk=8)[0]                      # [3, 8, 96, 96]
+    out = torch.empty(8, 96, 96, 4, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.avdf_video_prep(fr.cuda().data_ptr(), out.data_ptr(), 5, 224, 200, 8, 96, st), "prep")
+    assert torch.equal(out[..., :3].cpu(), ref.permute(1, 2, 3, 0)) and float(out[..., 3].abs().max()) == 0.0
+    x = torch.randn(4, 12, 18, 8, generator=g)
+    for p in (2, 3):
+        y = torch.empty(4, 12 // p, 18 // p, 8, device="cuda")
+        check(lib.avdf_maxpool_hw(x.cuda().data_ptr(), y.data_ptr(), 4, 12, 18, 8, p, st), "pool")
+        r = torch.nn.functional.max_pool3d(x.permute(3, 0, 1, 2)[None], (1, p, p))[0].permute(1, 2, 3, 0)
+        assert torch.equal(y.cpu(), r)
+
+
+@pytest.mark.parametrize("batch_norm", [False, True])
+def test_c3d_encoder_matches_torch_restatement(batch_norm):
+    from oracle import c3d_ref as R
+    m = _c3d_model(batch_norm)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    video = torch.rand(1, 3, 4, 96, 96, generator=g)
+    ref = R.encoder_forward(sd, video)
+    got = m.cuda()(video.cuda()).cpu()
+    assert got.shape == ref.shape == (1, 256, 4)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"C3D encoder bn={batch_norm}: rel err {err:.2e}")
+    assert err < 1e-4
+
+
+def test_video_features_chunking_and_tail_trim():
+    """chunk/pad/stitch rule on a small chunk size (the stitch logic is size-independent) + exact tail trimming."""
+    from audio_visual_deepfake_detection_amd.extractors import c3d as C
+    from oracle import c3d_ref as R
+    m = _c3d_model(False)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    g = torch.Generator().manual_seed(9)
+    fr = torch.randint(0, 256, (21, 120, 100, 3), generator=g, dtype=torch.uint8)
+    old = C.CHUNK
+    C.CHUNK = 16
+    try:
+        assert [c[2] for c in C.chunk_plan(32, 16)] == [16, 16, 0]
+        got_trim = C.video_features(fr.cuda(), m, trim_tail=True).cpu()
+        got_full = C.video_features(fr.cuda(), m, trim_tail=False).cpu()
+    finally:
+        C.CHUNK = old
+    ref = R.video_features(sd, fr, chunk=16)
+    assert got_full.shape == ref.shape == (21, 256)
+    assert torch.equal(got_trim, got_full)                       # trimming the all-zero tail is exact
+    err = float((got_full - ref).abs().max() / ref.abs().max())
+    print(f"video_features: rel err {err:.2e}")
+    assert err < 1e-4
