@@ -28,6 +28,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+// phase-timestamp hook for tools/probe (empty in the product build)
+#ifndef AVDF_PROBE
+#define AVDF_PROBE(slot)
+#endif
+
 namespace {
 
 template <int N>
@@ -77,6 +82,54 @@ __device__ __forceinline__ void kgroup_reduce(floatx16 (&acc)[NACC], float* red,
   }
 }
 
+// q-th float4 of a [rows][W4 float4] tile -> (row, c4).  A half-wave covers 4 rows x 8 float4 columns, so
+// the 32 lanes that scatter the same component of their float4 into a row-major LDS tile whose row stride is
+// = 1 (mod 32) hit 32 different banks (a plain row-major walk is a 4-way conflict); a wave still reads
+// 8 x 128 contiguous bytes from HBM/L2.
+template <int W4>
+__device__ __forceinline__ void tile_coord(int q, int& row, int& c4) {
+  if constexpr (W4 % 8 == 0) {
+    constexpr int CB = W4 / 8;
+    const int l = q & 63, wv = q >> 6;
+    row = (wv / CB) * 8 + (l & 3) + 4 * (l >> 5);
+    c4 = (wv % CB) * 8 + ((l >> 2) & 7);
+  } else {
+    row = q / W4;
+    c4 = q % W4;
+  }
+}
+constexpr int round8(int a) { return (a + 7) / 8 * 8; }
+
+// Cooperative epilogue: every K-group parks its accumulators in LDS as a [KG][BM][BN+4] tile (aliases the
+// operand buffers), then ALL threads of the workgroup sum the groups and hand one float4 of a row to `emit`
+// (row-contiguous 16-byte stores instead of 4-byte stores from one K-group's waves only).
+template <int BM, int BN, int KG, int WN, int MI, int NI, class Emit>
+__device__ __forceinline__ void tile_epilogue(floatx16 (&acc)[MI * NI], float* smem, int kg, int wm, int wn, int li,
+                                              int lh, int tid, Emit&& emit) {
+  constexpr int LDC = BN + 4, NT = 256 * KG;
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        smem[(kg * BM + row) * LDC + (wn * NI + ni) * 32 + li] = acc[mi * NI + ni][r];
+      }
+  __syncthreads();
+  for (int q = tid; q < BM * BN / 4; q += NT) {
+    const int row = q / (BN / 4), c = (q % (BN / 4)) * 4;
+    float4 v = *reinterpret_cast<const float4*>(smem + row * LDC + c);
+#pragma unroll
+    for (int g = 1; g < KG; ++g) {
+      const float4 u = *reinterpret_cast<const float4*>(smem + (g * BM + row) * LDC + c);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    emit(row, c, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -96,9 +149,9 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   constexpr int KB = KC * KS;
   constexpr int LDB = KB + 1;
   constexpr int A4 = KC / 4, B4 = KB / 4;
-  constexpr int NA = (RA * A4 + NT - 1) / NT, NB = (BN * B4 + NT - 1) / NT;
+  constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (BN * B4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = BN * LDB;
-  constexpr int SM = cmax(AS + BSZ, (KG - 1) * BM * BN);
+  constexpr int SM = cmax(AS + BSZ, KG * BM * (BN + 4));
   constexpr int KCG = KC / KG;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
@@ -122,10 +175,11 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   auto load_tile = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * NT;
+      int row, c4;
+      tile_coord<A4>(tid + i * NT, row, c4);
       float4 v = zero4();
-      if (q < RA * A4) {
-        const int row = q / A4, c = c0 + (q % A4) * 4;
+      if (row < RA) {
+        const int c = c0 + c4 * 4;
         const int tr = t0 * S - P + row;
         if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + tr) * ldx + c);
       }
@@ -133,10 +187,11 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * NT;
+      int row, c4;
+      tile_coord<B4>(tid + i * NT, row, c4);
       float4 v = zero4();
-      if (q < BN * B4) {
-        const int n = n0 + q / B4, e = c0 * KS + (q % B4) * 4;
+      if (row < BN) {
+        const int n = n0 + row, e = c0 * KS + c4 * 4;
         if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * ldw + e);
       }
       rb.v[i] = v;
@@ -145,26 +200,30 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * NT;
-      if (q < RA * A4) {
-        float* d = As + (q / A4) * LDA + (q % A4) * 4;
+      int row, c4;
+      tile_coord<A4>(tid + i * NT, row, c4);
+      if (row < RA) {
+        float* d = As + row * LDA + c4 * 4;
         d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * NT;
-      if (q < BN * B4) {
-        float* d = Bs + (q / B4) * LDB + (q % B4) * 4;
+      int row, c4;
+      tile_coord<B4>(tid + i * NT, row, c4);
+      if (row < BN) {
+        float* d = Bs + row * LDB + c4 * 4;
         d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
       }
     }
   };
 
   const int nk = (Cin + KC - 1) / KC;
+  AVDF_PROBE(0);
   load_tile(0);
   store_tile();
   __syncthreads();
+  AVDF_PROBE(1);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
     const float* Ag = As + kg * KCG;
@@ -188,34 +247,38 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       }
     }
     __syncthreads();
+    AVDF_PROBE(2 + 2 * kt);
     if (kt + 1 < nk) {
       store_tile();
       __syncthreads();
     }
+    AVDF_PROBE(3 + 2 * kt);
   }
-  kgroup_reduce<MI * NI, KG>(acc, smem, kg, w4, lane);
-  if (kg != 0) return;
-
+  AVDF_PROBE(14);
+  const bool vec = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                   (ypre == nullptr || (reinterpret_cast<uintptr_t>(ypre) & 15) == 0);
+  tile_epilogue<BM, BN, KG, WN, MI, NI>(acc, smem, kg, wm, wn, li, lh, tid, [&](int row_, int c, float4 v) {
+    const int t = t0 + row_, n = n0 + c;
+    if (t >= Tout || n >= Cout) return;
+    const size_t row = (size_t)b * Tout + t;
+    const float m = mask ? mask[row] : 1.f;
+    if (vec && n + 3 < Cout) {
+      if (bias) { const float4 bb = ld4(bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+      if (ypre) *reinterpret_cast<float4*>(ypre + row * ldy + n) = v;
+      v.x = act_f(v.x, act) * m; v.y = act_f(v.y, act) * m; v.z = act_f(v.z, act) * m; v.w = act_f(v.w, act) * m;
+      *reinterpret_cast<float4*>(y + row * ldy + n) = v;
+    } else {
+      const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + (wn * NI + ni) * 32 + li;
-      if (n >= Cout) continue;
-      const float bn = bias ? bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = t0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (t >= Tout) continue;
-        const size_t row = (size_t)b * Tout + t;
-        float v = acc[mi * NI + ni][r] + bn;
-        if (ypre) ypre[row * ldy + n] = v;
-        v = act_f(v, act);
-        if (mask) v *= mask[row];
-        y[row * ldy + n] = v;
+      for (int j = 0; j < 4; ++j) {
+        if (n + j >= Cout) break;
+        float u = e[j] + (bias ? bias[n + j] : 0.f);
+        if (ypre) ypre[row * ldy + n + j] = u;
+        y[row * ldy + n + j] = act_f(u, act) * m;
       }
     }
-  }
+  });
+  AVDF_PROBE(15);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -234,9 +297,9 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   constexpr int LDA = KC + 1;
   constexpr int LDB = BN * KS;
   constexpr int A4 = KC / 4, B4 = LDB / 4;
-  constexpr int NA = (RA * A4 + NT - 1) / NT, NB = (KC * B4 + NT - 1) / NT;
+  constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (KC * B4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = KC * LDB;
-  constexpr int SM = cmax(AS + BSZ, (KG - 1) * BM * BN);
+  constexpr int SM = cmax(AS + BSZ, KG * BM * (BN + 4));
   constexpr int KCG = KC / KG;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
@@ -274,10 +337,11 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   auto load_tile = [&](int nk0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * NT;
+      int rr, c4;
+      tile_coord<A4>(tid + i * NT, rr, c4);
       float4 v = zero4();
-      if (q < RA * A4) {
-        const int t = tA0 + q / A4, n = nk0 + (q % A4) * 4;
+      if (rr < RA) {
+        const int t = tA0 + rr, n = nk0 + c4 * 4;
         if (t >= 0 && t < Tout && n < Cout) {
           const size_t row = (size_t)b * Tout + t;
           v = grad_prologue(dy, mask, ypre, row, row * Cout + n, act);
@@ -299,9 +363,10 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int q = tid + i * NT;
-      if (q < RA * A4) {
-        float* d = As + (q / A4) * LDA + (q % A4) * 4;
+      int rr, c4;
+      tile_coord<A4>(tid + i * NT, rr, c4);
+      if (rr < RA) {
+        float* d = As + rr * LDA + c4 * 4;
         d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
       }
     }
@@ -346,22 +411,20 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
       __syncthreads();
     }
   }
-  kgroup_reduce<MI * NI, KG>(acc, smem, kg, w4, lane);
-  if (kg != 0) return;
-
+  const bool vec = ((Cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+  tile_epilogue<BM, BN, KG, WN, MI, NI>(acc, smem, kg, wm, wn, li, lh, tid, [&](int row_, int cc, float4 v) {
+    const int tp = tp0 + row_, c = c0 + cc;
+    if (tp >= Tin || c >= Cin) return;
+    float* o = dx + ((size_t)b * Tin + tp) * Cin + c;
+    if (vec && c + 3 < Cin) {
+      *reinterpret_cast<float4*>(o) = v;
+    } else {
+      const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int c = c0 + (wn * NI + ni) * 32 + li;
-      if (c >= Cin) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tp = tp0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (tp >= Tin) continue;
-        dx[((size_t)b * Tin + tp) * Cin + c] = acc[mi * NI + ni][r];
-      }
+      for (int j = 0; j < 4; ++j)
+        if (c + j < Cin) o[j] = e[j];
     }
+  });
 }
 
 // ------------------------------------------------------------------------------------------
