@@ -16,6 +16,48 @@ from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator, Segmentand
 from ... import ops
 
 
+_GAP_CACHE = {}
+
+
+def gap_levels(fpn_feats, fpn_masks):
+    """The FPN levels of a batch as ONE sequence [B, sum(T_l + 1), C]: an all-zero row after every level plays
+    the zero padding of that level's k3 convs, so the heads (weights shared across levels, av_fd_no_recon.py:75-89,
+    144-159) run as one launch per layer instead of one per level.  Returns (x, mask with zeros at the gap rows,
+    int64 index of the real rows in level order, 0/1 row vector that is 0 only at the gap rows: LayerNorm+ReLU turn
+    a zero row into relu(beta), so the gaps are re-zeroed after every norm -- masked real rows are NOT, as in the
+    reference)."""
+    B, _, C = fpn_feats[0].shape
+    dev = fpn_feats[0].device
+    lens = tuple(int(f.shape[1]) for f in fpn_feats)
+    key = (B, C, lens, dev)
+    hit = _GAP_CACHE.get(key)
+    if hit is None:
+        idx, off = [], 0
+        for n in lens:
+            idx.append(torch.arange(off, off + n))
+            off += n + 1
+        idx = torch.cat(idx)
+        keep = torch.zeros((B, off), dtype=torch.float32)
+        keep[:, idx] = 1.0
+        hit = (torch.zeros((B, 1, C), dtype=torch.float32, device=dev), torch.zeros((B, 1), dtype=torch.float32, device=dev),
+               idx.to(dev), keep.to(dev))
+        _GAP_CACHE[key] = hit
+    z, zm, idx, keep = hit
+    xs, ms = [], []
+    for f, m in zip(fpn_feats, fpn_masks):
+        xs += [f, z]
+        ms += [m, zm]
+    return torch.cat(xs, dim=1), torch.cat(ms, dim=1), idx, keep
+
+
+def split_levels(y, lens):
+    out, off = tuple(), 0
+    for n in lens:
+        out += (y[:, off:off + n],)
+        off += n + 1
+    return out
+
+
 class PtTransformerClsHead(nn.Module):
     """Shared classification head (av_fd_no_recon.py:13-89): 2 x [conv k3 -> LN -> ReLU] -> conv k3."""
 
@@ -35,16 +77,18 @@ class PtTransformerClsHead(nn.Module):
             for idx in empty_cls:
                 torch.nn.init.constant_(self.cls_head.conv.bias[idx], -(math.log((1 - 1e-6) / 1e-6)))
 
+    def forward_gapped(self, x, gmask, keep):
+        """All levels at once on the gapped sequence of `gap_levels`: [B, Tg, C] -> [B, Tg, nc]."""
+        cur = x
+        for idx in range(len(self.head)):
+            cur, _ = self.head[idx](cur, gmask)
+            cur = ops.scale_rows(self.norm[idx](cur, relu=True), keep)         # gap rows back to zero
+        return ops.smallconv(cur, self.cls_head.conv.weight, self.cls_head.conv.bias, gmask)
+
     def forward(self, fpn_feats, fpn_masks):
         assert len(fpn_feats) == len(fpn_masks)
-        out = tuple()
-        for feat, mask in zip(fpn_feats, fpn_masks):
-            cur = feat
-            for idx in range(len(self.head)):
-                cur, _ = self.head[idx](cur, mask)
-                cur = self.norm[idx](cur, relu=True)
-            out += (ops.smallconv(cur, self.cls_head.conv.weight, self.cls_head.conv.bias, mask),)   # [B,T_l,nc]
-        return out
+        x, gmask, _, keep = gap_levels(fpn_feats, fpn_masks)
+        return split_levels(self.forward_gapped(x, gmask, keep), [f.shape[1] for f in fpn_feats])
 
 
 class PtTransformerRegHead(nn.Module):
@@ -64,17 +108,21 @@ class PtTransformerRegHead(nn.Module):
         self.scale = nn.ModuleList([Scale() for _ in range(fpn_levels)])
         self.offset_head = MaskedConv1D(feat_dim, 2, kernel_size, stride=1, padding=kernel_size // 2)
 
+    def forward_gapped(self, x, gmask, keep, lens):
+        cur = x
+        for idx in range(len(self.head)):
+            cur, _ = self.head[idx](cur, gmask)
+            cur = ops.scale_rows(self.norm[idx](cur, relu=True), keep)
+        y = ops.smallconv(cur, self.offset_head.conv.weight, self.offset_head.conv.bias, gmask)
+        # per-level Scale then ReLU (av_fd_no_recon.py:155-156) as one row-scale vector over the gapped sequence
+        rs = torch.cat([self.scale[l].scale.reshape(1).expand(n + 1) for l, n in enumerate(lens)])
+        return torch.relu(y * rs[None, :, None])
+
     def forward(self, fpn_feats, fpn_masks):
         assert len(fpn_feats) == len(fpn_masks) == self.fpn_levels
-        out = tuple()
-        for l, (feat, mask) in enumerate(zip(fpn_feats, fpn_masks)):
-            cur = feat
-            for idx in range(len(self.head)):
-                cur, _ = self.head[idx](cur, mask)
-                cur = self.norm[idx](cur, relu=True)
-            out += (ops.smallconv(cur, self.offset_head.conv.weight, self.offset_head.conv.bias, mask,
-                                  self.scale[l].scale),)                                              # [B,T_l,2]
-        return out
+        lens = [f.shape[1] for f in fpn_feats]
+        x, gmask, _, keep = gap_levels(fpn_feats, fpn_masks)
+        return split_levels(self.forward_gapped(x, gmask, keep, lens), lens)
 
 
 @register_meta_arch("AVLocPointTransformerRecoveryNoNormNorecon")
@@ -240,12 +288,12 @@ class AVPtTransformerRecovery(nn.Module):
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
         feats, masks = self.backbone(x, reco_x, mask)
         fpn_feats, fpn_masks = self.neck(feats, masks)
-        out_cls = self.cls_head(fpn_feats, fpn_masks)
-        out_off = self.reg_head(fpn_feats, fpn_masks)
-        logits = torch.cat([c.squeeze(-1) for c in out_cls], dim=1)
-        offsets = torch.cat(out_off, dim=1)
+        lens = [int(f.shape[1]) for f in fpn_feats]
+        gx, gmask, gidx, keep = gap_levels(fpn_feats, fpn_masks)
+        logits = self.cls_head.forward_gapped(gx, gmask, keep).index_select(1, gidx).squeeze(-1)
+        offsets = self.reg_head.forward_gapped(gx, gmask, keep, lens).index_select(1, gidx)
         pmask = torch.cat(fpn_masks, dim=1)
-        return logits, offsets, pmask, cls_scores, [int(f.shape[1]) for f in fpn_feats]
+        return logits, offsets, pmask, cls_scores, lens
 
     def forward(self, video_list):
         x, mask = self.preprocessing(video_list)
