@@ -5,6 +5,7 @@
 //     (libs/modeling/blocks.py:1508-1516);
 //   * max+avg pooling over T (libs/modeling/blocks.py:1610-1614).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -67,18 +68,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
 }
 
 // ws layout: [gridDim.x][2*C]  (per block: dgamma partials, then dbeta partials)
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(
+// NW waves per workgroup (one row per wave at a time); the per-channel dgamma/dbeta partials of the NW waves are
+// folded in LDS, so only gridDim.x workgroups emit atomics / workspace rows.
+template <int NV, int NW>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
     float* __restrict__ dx, float* __restrict__ ws, float* __restrict__ dg_atomic, float* __restrict__ db_atomic,
     int M, int C, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2][C]
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][2][C]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) { ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j]; }
-  for (int row = blockIdx.x * 4 + wid; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * NW + wid; row < M; row += gridDim.x * NW) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     float4 xh[NV], gy[NV];
     float s1 = 0.f, s2 = 0.f;
@@ -129,11 +132,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+  for (int i = threadIdx.x; i < 2 * C; i += 64 * NW) {
     const int which = i / C, c = i % C;
     float s = 0.f;
 #pragma unroll
-    for (int w_ = 0; w_ < 4; ++w_) s += red[(size_t)(w_ * 2 + which) * C + c];
+    for (int w_ = 0; w_ < NW; ++w_) s += red[(size_t)(w_ * 2 + which) * C + c];
     if (dg_atomic) atomicAdd((which == 0 ? dg_atomic : db_atomic) + c, s);   // accumulate path: no second kernel
     else ws[(size_t)blockIdx.x * 2 * C + i] = s;
   }
@@ -251,9 +254,15 @@ extern "C" int avdf_layernorm_fwd(const float* x, const float* gamma, const floa
   return AVDF_OK;
 }
 
-static int ln_bwd_blocks(int M) { int g = cdiv(M, 4); return g < kLnBwdBlocks ? g : kLnBwdBlocks; }
+static int ln_bwd_waves(int C) { return C <= 256 ? 16 : (C <= 512 ? 8 : 4); }
+static int ln_bwd_blocks(int M, int C) {
+  static const char* e = getenv("AVDF_LN_BWD_BLOCKS");      // tuning override for tools/pw_bench.py
+  const int cap = e ? atoi(e) : kLnBwdBlocks;
+  int g = cdiv(M, ln_bwd_waves(C));
+  return g < cap ? g : cap;
+}
 
-extern "C" int64_t avdf_layernorm_bwd_ws(int M, int C) { return (int64_t)2 * ln_bwd_blocks(M) * C; }
+extern "C" int64_t avdf_layernorm_bwd_ws(int M, int C) { return (int64_t)2 * ln_bwd_blocks(M, C) * C; }
 
 extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
                                   const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
@@ -264,13 +273,14 @@ extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* 
   AVDF_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm_bwd: gamma/beta");
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && (!gamma || (aligned16(gamma) && aligned16(beta))), "layernorm_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  const int G = ln_bwd_blocks(M);
+  const int G = ln_bwd_blocks(M, C);
   const bool atomic = accumulate && dgamma && dbeta;
   float* dga = atomic ? dgamma : nullptr;
   float* dba = atomic ? dbeta : nullptr;
-#define LN_BWD(NV_) hipLaunchKernelGGL(ln_bwd_kernel<NV_>, dim3(G), dim3(256), (size_t)8 * C * sizeof(float), st, \
-                                      dy, x, gamma, beta, mean, rstd, dx, ws, dga, dba, M, C, relu)
-  if (C <= 256) LN_BWD(1); else if (C <= 512) LN_BWD(2); else if (C <= 1024) LN_BWD(4); else LN_BWD(8);
+#define LN_BWD(NV_, NW_) hipLaunchKernelGGL((ln_bwd_kernel<NV_, NW_>), dim3(G), dim3(64 * NW_),                 \
+                                           (size_t)2 * NW_ * C * sizeof(float), st, dy, x, gamma, beta, mean, rstd, \
+                                           dx, ws, dga, dba, M, C, relu)
+  if (C <= 256) LN_BWD(1, 16); else if (C <= 512) LN_BWD(2, 8); else if (C <= 1024) LN_BWD(4, 4); else LN_BWD(8, 4);
 #undef LN_BWD
   AVDF_CHECK_LAUNCH("layernorm_bwd");
   if (dgamma && !atomic) {

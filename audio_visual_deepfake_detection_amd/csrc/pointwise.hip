@@ -4,6 +4,7 @@
 //   residual + AffineDropPath (blocks.py:1311-1313,1397-1439), nearest resampling
 //   (backbones.py:487,490; necks.py:78-80), [B,C,T] <-> [B,T,C] transpose at the plugin boundary.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -15,6 +16,16 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
 constexpr int kPartialBlocks = 128;
+// The fused (atomic) backward kernels: float atomics cost ~30 ns each on this part, so the per-channel sums are
+// first folded over a 1024-thread workgroup in LDS and at most kFusedBlocks workgroups touch the gradient
+// (measured, B=8 T=768 C=256: 768 x 256-thread blocks 25 us -> 128 x 1024 <10 us).
+constexpr int kFusedThreads = 1024;
+static int fused_blocks(long elems4) {
+  static const char* e = getenv("AVDF_FUSED_BLOCKS");      // tuning override for tools/pw_bench.py
+  const long cap = e ? atoi(e) : 128;
+  const long g = (elems4 + kFusedThreads - 1) / kFusedThreads;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
 
 // weights of 4 consecutive channels: w[c..c+3][0..2] = 12 contiguous floats -> per-tap float4
 __device__ __forceinline__ void load_dw_taps(const float* __restrict__ w, int c, float4 tap[3]) {
@@ -113,18 +124,18 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __r
 // Fused backward for the accumulate path: dx by gather, dw by per-thread partial sums (a thread keeps
 // the same channel quad over the whole grid-stride loop because gridDim*256 is a multiple of C/4),
 // block reduction over the row groups in LDS, then one float atomic per (channel, tap) and block.
-__global__ __launch_bounds__(256) void dwconv_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(kFusedThreads) void dwconv_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ w, const float* __restrict__ mask,
                                                                float* __restrict__ dx, float* __restrict__ dw,
                                                                int B, int Tin, int Tout, int C, int S) {
-  __shared__ float red[256 * 12];
+  __shared__ float red[kFusedThreads * 12];
   const int C4 = C >> 2;
-  const int c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4) * 4;
+  const int c = (int)(((long)blockIdx.x * kFusedThreads + threadIdx.x) % C4) * 4;
   float4 tap[3];
   load_dw_taps(w, c, tap);
   if (dx) {
     const long total = (long)B * Tin * C4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * kFusedThreads + threadIdx.x; i < total; i += (long)gridDim.x * kFusedThreads) {
       const long bt = i / C4;
       const int tp = (int)(bt % Tin);
       const long b = bt / Tin;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fused_kernel(const float* __re
   }
   float4 a0 = f4(0.f), a1 = f4(0.f), a2 = f4(0.f);
   const long rows = (long)B * Tout;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * C4; i += (long)gridDim.x * 256) {
+  for (long i = (long)blockIdx.x * kFusedThreads + threadIdx.x; i < rows * C4; i += (long)gridDim.x * kFusedThreads) {
     const long r = i / C4;
     const int t = (int)(r % Tout);
     const long b = r / Tout;
@@ -161,29 +172,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fused_kernel(const float* __re
   d[0] = a0.x; d[1] = a1.x; d[2] = a2.x; d[3] = a0.y; d[4] = a1.y; d[5] = a2.y;
   d[6] = a0.z; d[7] = a1.z; d[8] = a2.z; d[9] = a0.w; d[10] = a1.w; d[11] = a2.w;
   __syncthreads();
-  // threads tid, tid+C4, tid+2*C4 ... of this block share a channel quad (C4 divides 256)
+  // threads tid, tid+C4, tid+2*C4 ... of this block share a channel quad (C4 divides the block size)
   const int per = C4 * 12;
-  for (int e = threadIdx.x; e < per; e += 256) {
+  for (int e = threadIdx.x; e < per; e += kFusedThreads) {
     float s_ = 0.f;
-    for (int q = e; q < 256 * 12; q += per) s_ += red[q];
-    const int quad = ((blockIdx.x * 256) % C4 + e / 12) % C4;
+    for (int q = e; q < kFusedThreads * 12; q += per) s_ += red[q];
+    const int quad = ((blockIdx.x * kFusedThreads) % C4 + e / 12) % C4;
     atomicAdd(dw + quad * 12 + (e % 12), s_);
   }
 }
 
 // Fused backward of out = a*ma + scale*keep*(r*mr) for the accumulate path: da, dr and an atomically
 // accumulated dscale (same per-thread channel-quad invariant as above).
-__global__ __launch_bounds__(256) void affine_residual_bwd_fused_kernel(
+__global__ __launch_bounds__(kFusedThreads) void affine_residual_bwd_fused_kernel(
     const float* __restrict__ dout, const float* __restrict__ ma, const float* __restrict__ r,
     const float* __restrict__ mr, const float* __restrict__ scale, const float* __restrict__ keep,
     float* __restrict__ da, float* __restrict__ dr, float* __restrict__ dscale, int B, int T, int C) {
-  __shared__ float red[256 * 4];
+  __shared__ float red[kFusedThreads * 4];
   const int C4 = C >> 2;
-  const int c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4) * 4;
+  const int c = (int)(((long)blockIdx.x * kFusedThreads + threadIdx.x) % C4) * 4;
   const float4 sc = ld4(scale + c);
   float4 ds = f4(0.f);
   const long total = (long)B * T * C4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = (long)blockIdx.x * kFusedThreads + threadIdx.x; i < total; i += (long)gridDim.x * kFusedThreads) {
     const long bt = i / C4;
     const long b = bt / T;
     const float4 g = ld4(dout + bt * C + c);
@@ -197,10 +208,10 @@ __global__ __launch_bounds__(256) void affine_residual_bwd_fused_kernel(
   d[0] = ds.x; d[1] = ds.y; d[2] = ds.z; d[3] = ds.w;
   __syncthreads();
   const int per = C4 * 4;
-  for (int e = threadIdx.x; e < per; e += 256) {
+  for (int e = threadIdx.x; e < per; e += kFusedThreads) {
     float s_ = 0.f;
-    for (int q = e; q < 256 * 4; q += per) s_ += red[q];
-    const int quad = ((blockIdx.x * 256) % C4 + e / 4) % C4;
+    for (int q = e; q < kFusedThreads * 4; q += per) s_ += red[q];
+    const int quad = ((blockIdx.x * kFusedThreads) % C4 + e / 4) % C4;
     atomicAdd(dscale + quad * 4 + (e % 4), s_);
   }
 }
@@ -438,9 +449,9 @@ extern "C" int avdf_dwconv_bwd(const float* dy, const float* x, const float* w, 
   AVDF_REQUIRE((stride == 1 || stride == 2) && Tout == (Tin - 1) / stride + 1, "dwconv_bwd: stride/Tout");
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w) && (!dx || aligned16(dx)), "dwconv_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  if (accumulate && dw && (256 % (C / 4) == 0)) {
+  if (accumulate && dw && (kFusedThreads % (C / 4) == 0)) {
     // accumulate path (engine): one fused kernel, dw by float atomics straight into the gradient buffer
-    hipLaunchKernelGGL(dwconv_bwd_fused_kernel, dim3(grid_for((long)B * Tin * C / 4 / 2)), dim3(256), 0, st,
+    hipLaunchKernelGGL(dwconv_bwd_fused_kernel, dim3(fused_blocks((long)B * Tin * C / 4)), dim3(kFusedThreads), 0, st,
                        dy, x, w, mask, dx, dw, B, Tin, Tout, C, stride);
     AVDF_CHECK_LAUNCH("dwconv_bwd_fused");
     return AVDF_OK;
@@ -499,8 +510,8 @@ extern "C" int avdf_affine_residual_bwd(const float* dout, const float* ma, cons
   REQ_C4("affine_residual_bwd", C);
   AVDF_REQUIRE(aligned16(dout) && aligned16(r) && aligned16(scale) && (!da || aligned16(da)) && (!dr || aligned16(dr)), "affine_residual_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  if (accumulate && dscale && (256 % (C / 4) == 0)) {
-    hipLaunchKernelGGL(affine_residual_bwd_fused_kernel, dim3(grid_for((long)B * T * C / 4 / 2)), dim3(256), 0, st,
+  if (accumulate && dscale && (kFusedThreads % (C / 4) == 0)) {
+    hipLaunchKernelGGL(affine_residual_bwd_fused_kernel, dim3(fused_blocks((long)B * T * C / 4)), dim3(kFusedThreads), 0, st,
                        dout, ma, r, mr, scale, keep, da, dr, dscale, B, T, C);
     AVDF_CHECK_LAUNCH("affine_residual_bwd_fused");
     return AVDF_OK;

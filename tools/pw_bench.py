@@ -1,0 +1,34 @@
+"""Micro-benchmark of the HBM-bound backward kernels at the exp10 block shape (B=8, T=768, C=256).
+    python tools/pw_bench.py   (env AVDF_LN_BWD_BLOCKS / AVDF_FUSED_DIV override the launch heuristics)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from audio_visual_deepfake_detection_amd._lib import lib, check
+from tools.gemm_bench import timeit
+
+dev = torch.device("cuda:0")
+B, T, C = 8, int(os.environ.get("T", 768)), 256
+st = lambda: torch.cuda.current_stream().cuda_stream
+x = torch.randn(B, T, C, device=dev); dy = torch.randn(B, T, C, device=dev); dx = torch.empty_like(x)
+g = torch.randn(C, device=dev); b = torch.randn(C, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+mean = torch.randn(B * T, device=dev); rstd = torch.rand(B * T, device=dev) + 0.5
+ws = torch.empty(int(lib.avdf_layernorm_bwd_ws(B * T, C)) + 4096 * C, device=dev)
+P = lambda t: None if t is None else t.data_ptr()
+for acc in (1, 0):
+    us = timeit(lambda: check(lib.avdf_layernorm_bwd(P(dy), P(x), P(g), P(b), P(mean), P(rstd), P(dx), P(dg), P(db), P(ws), B * T, C, 0, acc, st()), "ln"))
+    print(f"ln_bwd accumulate={acc}: {us:.2f} us  ({4*B*T*C*3/us/1e3:.0f} GB/s)")
+w = torch.randn(C, 1, 3, device=dev); dw = torch.zeros(C, 1, 3, device=dev); mask = torch.ones(B, T, device=dev)
+ws2 = torch.empty(int(lib.avdf_dwconv_bwd_ws(B, T, C)), device=dev)
+for acc in (1, 0):
+    us = timeit(lambda: check(lib.avdf_dwconv_bwd(P(dy), P(x), P(w), P(mask), P(dx), P(dw), P(ws2), B, T, T, C, 1, acc, st()), "dw"))
+    print(f"dwconv_bwd accumulate={acc}: {us:.2f} us")
+sc = torch.randn(C, device=dev); dsc = torch.zeros(C, device=dev); keep = torch.ones(B, device=dev); da = torch.empty_like(x); dr = torch.empty_like(x)
+ws3 = torch.empty(int(lib.avdf_affine_residual_bwd_ws(B, T, C)), device=dev)
+for acc in (1, 0):
+    us = timeit(lambda: check(lib.avdf_affine_residual_bwd(P(dy), P(mask), P(x), None, P(sc), P(keep), P(da), P(dr), P(dsc), P(ws3), B, T, C, acc, st()), "ar"))
+    print(f"affine_residual_bwd accumulate={acc}: {us:.2f} us")
+y = torch.empty_like(x)
+us = timeit(lambda: check(lib.avdf_layernorm_fwd(P(x), P(g), P(b), P(y), P(mean), P(rstd), B * T, C, 1e-5, 0, None, None, 0, st()), "lnf"))
+print(f"ln_fwd: {us:.2f} us")
+us = timeit(lambda: check(lib.avdf_scale_rows(P(x), P(mask), P(y), B * T, C, st()), "sr"))
+print(f"scale_rows (copy-like, 2x6MB): {us:.2f} us  ({4*B*T*C*2/us/1e3:.0f} GB/s)")
