@@ -73,6 +73,11 @@ SIGNATURES = {
     "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
     "avdf_wave_conv_c1": (I, [P, P, P, L, L, I, I, I, P]),
     "avdf_grouped_conv_pos": (I, [P, P, P, P, I, I, I, I, P]),
+    "avdf_chain_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_chain_bwd_ws": (L, [I, I, I]),
+    "avdf_chain_bwd_rows": (I, [I, I]),
+    "avdf_chain_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
+    "avdf_reduce_segments": (I, [P, I, I, I, P, P, P, P, I, P]),
     "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "avdf_video_prep": (I, [P, P, I, I, I, I, I, P]),
     "avdf_maxpool_hw": (I, [P, P, L, I, I, I, I, P]),

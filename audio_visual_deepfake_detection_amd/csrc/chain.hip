@@ -1,0 +1,393 @@
+// Fused "LayerNorm -> depthwise conv k3 (stride s) * mask -> LayerNorm" chains for the q / k / v inputs of the
+// conv-attention blocks, three branches per launch, forward and backward (gfx950).
+//
+// Replaces, per attention block, ln1 | lnq,lnk,lnv (libs/modeling/blocks.py:1307-1309, 866-868) followed by
+// query_conv/key_conv/value_conv (MaskedConv1D depthwise k3, blocks.py:239-262, 931-955) and
+// query_norm/key_norm/value_norm (blocks.py:1166-1173, 724-731) and their autograd backward: 7-9 launches
+// forward and ~13 backward become 1 + 2.  HBM-bound: one wave owns one token row (C <= 256: one float4 per lane),
+// row reductions are wave shuffles, the conv halo lives in LDS.
+//
+// Forward : z = LN_a(x) for the tile's rows (+1 halo each side) -> LDS; u[t] = sum_k z[t*s+k-1]*w[k] * mask[t];
+//           y = LN_b(u).  u and both LNs' (mean, rstd) are kept for the backward.
+// Backward: du = LN_b'(dy) * mask -> LDS; per input row dz = sum_k du[(t+1-k)/s] * w[k], dw[k] += du*z,
+//           dx += LN_a'(dz) summed over the branches that share the input; the per-channel parameter partials
+//           of a workgroup go to a workspace row that avdf_reduce_segments folds (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxSeg = 16;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z, a.w * b.w + c.w);
+}
+__device__ __forceinline__ float hsum4(float4 a) { return a.x + a.y + a.z + a.w; }
+__device__ __forceinline__ void load_taps(const float* __restrict__ w, int c, float4 tap[3]) {
+  const float4 a = ld4(w + c * 3), b = ld4(w + c * 3 + 4), d = ld4(w + c * 3 + 8);
+  tap[0] = make_float4(a.x, a.w, b.z, d.y);
+  tap[1] = make_float4(a.y, b.x, b.w, d.z);
+  tap[2] = make_float4(a.z, b.y, d.x, d.w);
+}
+
+struct ChainFwdArgs {
+  const float* x[3]; const float* ga[3]; const float* ba[3]; const float* w[3]; const float* gb[3]; const float* bb[3];
+  float* u[3]; float* y[3]; float* sa[3]; float* sb[3];
+};
+
+// grid (B * tiles, 3); TO output tokens per workgroup, NW waves
+template <int S, int TO, int NW>
+__global__ __launch_bounds__(64 * NW) void chain_fwd_kernel(ChainFwdArgs a, const float* __restrict__ mask, int B, int Tin,
+                                                            int Tout, int C, float eps, int tiles) {
+  constexpr int RZ = (TO - 1) * S + 3;
+  extern __shared__ __attribute__((aligned(16))) float zbuf[];      // [RZ][C]
+  const int br = blockIdx.y;
+  const int b = blockIdx.x / tiles, to0 = (blockIdx.x % tiles) * TO;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = lane * 4;
+  const bool act = c < C;
+  const float invC = 1.0f / (float)C;
+  const float* __restrict__ x = a.x[br];
+  const int ti_lo = to0 * S - 1;
+  {
+    float4 g = f4(1.f), bt = f4(0.f);
+    if (act && a.ga[br]) { g = ld4(a.ga[br] + c); bt = ld4(a.ba[br] + c); }
+    float* mean_o = a.sa[br];
+    float* rstd_o = a.sa[br] + (size_t)B * Tin;
+#pragma unroll
+    for (int r0 = 0; r0 < RZ; r0 += NW) {
+      const int r = r0 + wid;
+      if (r >= RZ) break;
+      const int t = ti_lo + r;
+      float4 z = f4(0.f);
+      if (t >= 0 && t < Tin) {
+        const size_t row = (size_t)b * Tin + t;
+        const float4 v = act ? ld4(x + row * C + c) : f4(0.f);
+        const float mean = wave_sum(hsum4(v)) * invC;
+        const float4 d = act ? sub4(v, f4(mean)) : f4(0.f);
+        const float rstd = 1.0f / sqrtf(wave_sum(hsum4(mul4(d, d))) * invC + eps);
+        z = fma4(scl4(d, rstd), g, bt);
+        if (lane == 0 && t >= to0 * S && t < (to0 + TO) * S) { mean_o[row] = mean; rstd_o[row] = rstd; }
+      }
+      if (act) st4(zbuf + r * C + c, z);
+    }
+  }
+  __syncthreads();
+  float4 tap[3] = {f4(0.f), f4(0.f), f4(0.f)};
+  float4 g = f4(1.f), bt = f4(0.f);
+  if (act) {
+    load_taps(a.w[br], c, tap);
+    if (a.gb[br]) { g = ld4(a.gb[br] + c); bt = ld4(a.bb[br] + c); }
+  }
+  float* mean_o = a.sb[br];
+  float* rstd_o = a.sb[br] + (size_t)B * Tout;
+#pragma unroll
+  for (int i0 = 0; i0 < TO; i0 += NW) {
+    const int i = i0 + wid;
+    const int t_o = to0 + i;
+    if (i >= TO || t_o >= Tout) break;
+    const size_t row = (size_t)b * Tout + t_o;
+    float4 u = f4(0.f);
+    if (act) {
+      const float* zr = zbuf + (i * S) * C + c;
+      u = mul4(ld4(zr), tap[0]);
+      u = add4(u, mul4(ld4(zr + C), tap[1]));
+      u = add4(u, mul4(ld4(zr + 2 * C), tap[2]));
+      if (mask) u = scl4(u, mask[row]);
+      st4(a.u[br] + row * C + c, u);
+    }
+    const float mean = wave_sum(hsum4(u)) * invC;
+    const float4 d = act ? sub4(u, f4(mean)) : f4(0.f);
+    const float rstd = 1.0f / sqrtf(wave_sum(hsum4(mul4(d, d))) * invC + eps);
+    if (act) st4(a.y[br] + row * C + c, fma4(scl4(d, rstd), g, bt));
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
+struct ChainBwdArgs {
+  const float* dy[3]; const float* u[3]; const float* sb[3]; const float* x[3]; const float* sa[3];
+  const float* ga[3]; const float* ba[3]; const float* w[3]; const float* gb[3];
+  float* dx[3];
+};
+
+// ws row of a workgroup: [3 branches][7*C]: dgamma_a, dbeta_a, dw (c*3+k order, 3C), dgamma_b, dbeta_b
+template <int S, int TI, int NW>
+__global__ __launch_bounds__(64 * NW) void chain_bwd_kernel(ChainBwdArgs a, const float* __restrict__ mask,
+                                                            float* __restrict__ ws, int B, int Tin, int Tout, int C,
+                                                            int tiles, int store_mask) {
+  constexpr int RU = TI / S + 2;            // du rows a tile can touch
+  constexpr int NR1 = (RU + NW - 1) / NW;   // phase-1 rows per wave
+  constexpr int NR2 = TI / NW;              // phase-2 rows per wave
+  static_assert(TI % NW == 0 && TI % S == 0, "tile must split evenly");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dubuf = smem;                       // [RU][C]
+  float* red = smem + RU * C;                // [NW][7*C]
+  const int b = blockIdx.x / tiles, ti0 = (blockIdx.x % tiles) * TI;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = lane * 4;
+  const bool act = c < C;
+  const float invC = 1.0f / (float)C;
+  const int to_lo = ti0 == 0 ? 0 : (ti0 - 1 + S - 1) / S;
+  int to_hi = (ti0 + TI) / S;
+  if (to_hi > Tout - 1) to_hi = Tout - 1;
+  const size_t BTo = (size_t)B * Tout, BTi = (size_t)B * Tin;
+
+  float4 dxacc[NR2];
+#pragma unroll
+  for (int i = 0; i < NR2; ++i) dxacc[i] = f4(0.f);
+
+  for (int br = 0; br < 3; ++br) {
+    // ---- phase 1: du = LN_b'(dy) * mask for the output rows this tile's inputs feed ----------------
+    float4 dgb = f4(0.f), dbb = f4(0.f);
+    {
+      const float4 g = (act && a.gb[br]) ? ld4(a.gb[br] + c) : f4(1.f);
+      float4 dv[NR1], uv[NR1];
+      float mn[NR1], rs[NR1], mk[NR1];
+#pragma unroll
+      for (int j = 0; j < NR1; ++j) {
+        const int t_o = to_lo + wid + j * NW;
+        dv[j] = f4(0.f); uv[j] = f4(0.f); mn[j] = 0.f; rs[j] = 0.f; mk[j] = 0.f;
+        if (t_o <= to_hi) {
+          const size_t row = (size_t)b * Tout + t_o;
+          if (act) { dv[j] = ld4(a.dy[br] + row * C + c); uv[j] = ld4(a.u[br] + row * C + c); }
+          mn[j] = a.sb[br][row]; rs[j] = a.sb[br][BTo + row];
+          mk[j] = mask ? mask[row] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NR1; ++j) {
+        const int r = wid + j * NW;
+        const int t_o = to_lo + r;
+        if (t_o > to_hi) continue;
+        const float4 h = act ? scl4(sub4(uv[j], f4(mn[j])), rs[j]) : f4(0.f);
+        if (t_o * S >= ti0 && t_o * S < ti0 + TI) { dgb = fma4(dv[j], h, dgb); dbb = add4(dbb, dv[j]); }
+        const float4 gy = mul4(dv[j], g);
+        const float m1 = wave_sum(hsum4(gy)) * invC;
+        const float m2 = wave_sum(hsum4(mul4(gy, h))) * invC;
+        float4 du = scl4(sub4(sub4(gy, f4(m1)), scl4(h, m2)), rs[j] * mk[j]);
+        if (act) st4(dubuf + r * C + c, du);
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: per input row: dz, dw, LN_a' ----------------------------------------------------------
+    float4 dga = f4(0.f), dba = f4(0.f), dw0 = f4(0.f), dw1 = f4(0.f), dw2 = f4(0.f);
+    {
+      float4 g = f4(1.f), bt = f4(0.f), tap[3] = {f4(0.f), f4(0.f), f4(0.f)};
+      if (act) {
+        if (a.ga[br]) { g = ld4(a.ga[br] + c); bt = ld4(a.ba[br] + c); }
+        load_taps(a.w[br], c, tap);
+      }
+      float4 xv[NR2];
+      float mn[NR2], rs[NR2];
+#pragma unroll
+      for (int i = 0; i < NR2; ++i) {
+        const int t = ti0 + wid + i * NW;
+        xv[i] = f4(0.f); mn[i] = 0.f; rs[i] = 0.f;
+        if (t < Tin) {
+          const size_t row = (size_t)b * Tin + t;
+          if (act) xv[i] = ld4(a.x[br] + row * C + c);
+          mn[i] = a.sa[br][row]; rs[i] = a.sa[br][BTi + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NR2; ++i) {
+        const int t = ti0 + wid + i * NW;
+        if (t >= Tin) continue;
+        const float4 h = act ? scl4(sub4(xv[i], f4(mn[i])), rs[i]) : f4(0.f);
+        const float4 z = fma4(h, g, bt);
+        float4 dz = f4(0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int num = t + 1 - k;
+          if (num < 0 || (num % S) != 0) continue;
+          const int t_o = num / S;
+          if (t_o > to_hi || t_o < to_lo) continue;
+          const float4 du = act ? ld4(dubuf + (t_o - to_lo) * C + c) : f4(0.f);
+          dz = fma4(du, tap[k], dz);
+          if (k == 0) dw0 = fma4(du, z, dw0);
+          else if (k == 1) dw1 = fma4(du, z, dw1);
+          else dw2 = fma4(du, z, dw2);
+        }
+        dga = fma4(dz, h, dga);
+        dba = add4(dba, dz);
+        const float4 gz = mul4(dz, g);
+        const float m1 = wave_sum(hsum4(gz)) * invC;
+        const float m2 = wave_sum(hsum4(mul4(gz, h))) * invC;
+        dxacc[i] = add4(dxacc[i], scl4(sub4(sub4(gz, f4(m1)), scl4(h, m2)), rs[i]));
+      }
+    }
+    // ---- fold the waves' parameter partials, emit this workgroup's workspace row ------------------------
+    if (act) {
+      float* rw = red + (size_t)wid * 7 * C;
+      st4(rw + c, dga);
+      st4(rw + C + c, dba);
+      float* d = rw + 2 * C + c * 3;
+      d[0] = dw0.x; d[1] = dw1.x; d[2] = dw2.x; d[3] = dw0.y; d[4] = dw1.y; d[5] = dw2.y;
+      d[6] = dw0.z; d[7] = dw1.z; d[8] = dw2.z; d[9] = dw0.w; d[10] = dw1.w; d[11] = dw2.w;
+      st4(rw + 5 * C + c, dgb);
+      st4(rw + 6 * C + c, dbb);
+    }
+    __syncthreads();
+    {
+      float* wrow = ws + ((size_t)blockIdx.x * 3 + br) * 7 * C;
+      for (int e = threadIdx.x; e < 7 * C; e += 64 * NW) {
+        float s = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; ++w_) s += red[(size_t)w_ * 7 * C + e];
+        wrow[e] = s;
+      }
+    }
+    if ((store_mask >> br) & 1) {
+#pragma unroll
+      for (int i = 0; i < NR2; ++i) {
+        const int t = ti0 + wid + i * NW;
+        if (t < Tin && act) st4(a.dx[br] + ((size_t)b * Tin + t) * C + c, dxacc[i]);
+        dxacc[i] = f4(0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct SegArgs {
+  float* dst[kMaxSeg];
+  int len[kMaxSeg];
+  int nsrc[kMaxSeg];
+  int src[kMaxSeg][3];
+  int first[kMaxSeg + 1];       // prefix sum of len
+};
+
+// dst[s][i] (+)= sum_{rows r} sum_{j < nsrc[s]} ws[r*stride + src[s][j] + i]
+__global__ __launch_bounds__(1024) void reduce_segments_kernel(const float* __restrict__ ws, int nrow, int stride, SegArgs sa,
+                                                               int nseg, int accumulate) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int total = sa.first[nseg];
+  int s = 0;
+  float acc = 0.f;
+  if (col < total) {
+    while (col >= sa.first[s + 1]) ++s;
+    const int i = col - sa.first[s];
+    for (int j = 0; j < sa.nsrc[s]; ++j) {
+      const float* p = ws + sa.src[s][j] + i;
+      for (int r = ph; r < nrow; r += 16) acc += p[(size_t)r * stride];
+    }
+  }
+  red[ph][cl] = acc;
+  __syncthreads();
+  if (ph == 0 && col < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    float* o = sa.dst[s] + (col - sa.first[s]);
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+constexpr int kTile = 32, kWaves = 8;
+
+}  // namespace
+
+extern "C" int avdf_chain_fwd(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                              const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                              const float* mask, float* const* u, float* const* y, float* const* stats_a,
+                              float* const* stats_b, int B, int Tin, int Tout, int C, int stride, float eps,
+                              void* stream) {
+  AVDF_REQUIRE(x && w && u && y && stats_a && stats_b && gamma_a && beta_a && gamma_b && beta_b, "chain_fwd: null table");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && C > 0 && C % 4 == 0 && C <= 256, "chain_fwd: C must be a multiple of 4, <= 256 (%d)", C);
+  AVDF_REQUIRE(stride == 1 || stride == 2, "chain_fwd: stride must be 1 or 2");
+  AVDF_REQUIRE(Tout == (Tin - 1) / stride + 1, "chain_fwd: Tout=%d inconsistent with Tin=%d stride=%d", Tout, Tin, stride);
+  ChainFwdArgs a;
+  for (int i = 0; i < 3; ++i) {
+    AVDF_REQUIRE(x[i] && w[i] && u[i] && y[i] && stats_a[i] && stats_b[i], "chain_fwd: null branch pointer");
+    AVDF_REQUIRE((gamma_a[i] == nullptr) == (beta_a[i] == nullptr) && (gamma_b[i] == nullptr) == (beta_b[i] == nullptr),
+                 "chain_fwd: gamma/beta must come in pairs");
+    AVDF_REQUIRE(aligned16(x[i]) && aligned16(w[i]) && aligned16(u[i]) && aligned16(y[i]) && aligned16(gamma_a[i]) &&
+                     aligned16(beta_a[i]) && aligned16(gamma_b[i]) && aligned16(beta_b[i]),
+                 "chain_fwd: 16-byte alignment");
+    a.x[i] = x[i]; a.ga[i] = gamma_a[i]; a.ba[i] = beta_a[i]; a.w[i] = w[i]; a.gb[i] = gamma_b[i]; a.bb[i] = beta_b[i];
+    a.u[i] = u[i]; a.y[i] = y[i]; a.sa[i] = stats_a[i]; a.sb[i] = stats_b[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    constexpr int TO = kTile;
+    const int tiles = cdiv(Tout, TO);
+    hipLaunchKernelGGL((chain_fwd_kernel<1, TO, kWaves>), dim3(B * tiles, 3), dim3(64 * kWaves),
+                       (size_t)((TO - 1) + 3) * C * sizeof(float), st, a, mask, B, Tin, Tout, C, eps, tiles);
+  } else {
+    constexpr int TO = kTile / 2;
+    const int tiles = cdiv(Tout, TO);
+    hipLaunchKernelGGL((chain_fwd_kernel<2, TO, kWaves>), dim3(B * tiles, 3), dim3(64 * kWaves),
+                       (size_t)((TO - 1) * 2 + 3) * C * sizeof(float), st, a, mask, B, Tin, Tout, C, eps, tiles);
+  }
+  AVDF_CHECK_LAUNCH("chain_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int64_t avdf_chain_bwd_ws(int B, int Tin, int C) { return (int64_t)B * cdiv(Tin, kTile) * 21 * C; }
+extern "C" int avdf_chain_bwd_rows(int B, int Tin) { return B * cdiv(Tin, kTile); }
+
+extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, const float* const* stats_b,
+                              const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                              const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                              const float* mask, float* const* dx, int store_mask, float* ws, int B, int Tin, int Tout,
+                              int C, int stride, void* stream) {
+  AVDF_REQUIRE(dy && u && stats_b && x && stats_a && gamma_a && beta_a && w && gamma_b && dx && ws, "chain_bwd: null table");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && C > 0 && C % 4 == 0 && C <= 256, "chain_bwd: C must be a multiple of 4, <= 256 (%d)", C);
+  AVDF_REQUIRE(stride == 1 || stride == 2, "chain_bwd: stride must be 1 or 2");
+  AVDF_REQUIRE(Tout == (Tin - 1) / stride + 1, "chain_bwd: Tout inconsistent");
+  AVDF_REQUIRE((store_mask & 4) && store_mask > 0 && store_mask < 8, "chain_bwd: the last branch must close an input group");
+  ChainBwdArgs a;
+  for (int i = 0; i < 3; ++i) {
+    AVDF_REQUIRE(dy[i] && u[i] && stats_b[i] && x[i] && stats_a[i] && w[i], "chain_bwd: null branch pointer");
+    AVDF_REQUIRE(!((store_mask >> i) & 1) || dx[i], "chain_bwd: dx missing for a closing branch");
+    AVDF_REQUIRE(aligned16(dy[i]) && aligned16(u[i]) && aligned16(x[i]) && aligned16(w[i]) && aligned16(gamma_a[i]) &&
+                     aligned16(beta_a[i]) && aligned16(gamma_b[i]) && aligned16(dx[i]),
+                 "chain_bwd: 16-byte alignment");
+    a.dy[i] = dy[i]; a.u[i] = u[i]; a.sb[i] = stats_b[i]; a.x[i] = x[i]; a.sa[i] = stats_a[i];
+    a.ga[i] = gamma_a[i]; a.ba[i] = beta_a[i]; a.w[i] = w[i]; a.gb[i] = gamma_b[i]; a.dx[i] = dx[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = cdiv(Tin, kTile);
+  if (stride == 1) {
+    constexpr int RU = kTile + 2;
+    hipLaunchKernelGGL((chain_bwd_kernel<1, kTile, kWaves>), dim3(B * tiles), dim3(64 * kWaves),
+                       (size_t)(RU + kWaves * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
+  } else {
+    constexpr int RU = kTile / 2 + 2;
+    hipLaunchKernelGGL((chain_bwd_kernel<2, kTile, kWaves>), dim3(B * tiles), dim3(64 * kWaves),
+                       (size_t)(RU + kWaves * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
+  }
+  AVDF_CHECK_LAUNCH("chain_bwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,
+                                    const int* nsrc, const int* src_off /* [nseg][3] */, int accumulate, void* stream) {
+  AVDF_REQUIRE(ws && dst && len && nsrc && src_off && nrow > 0 && row_stride > 0, "reduce_segments: bad args");
+  AVDF_REQUIRE(nseg > 0 && nseg <= kMaxSeg, "reduce_segments: 1..%d segments", kMaxSeg);
+  SegArgs sa;
+  sa.first[0] = 0;
+  for (int s = 0; s < nseg; ++s) {
+    AVDF_REQUIRE(dst[s] && len[s] > 0 && nsrc[s] >= 1 && nsrc[s] <= 3, "reduce_segments: bad segment %d", s);
+    sa.dst[s] = dst[s]; sa.len[s] = len[s]; sa.nsrc[s] = nsrc[s];
+    for (int j = 0; j < 3; ++j) {
+      sa.src[s][j] = src_off[s * 3 + j];
+      AVDF_REQUIRE(j >= nsrc[s] || (sa.src[s][j] >= 0 && sa.src[s][j] + len[s] <= row_stride), "reduce_segments: source out of the row");
+    }
+    sa.first[s + 1] = sa.first[s] + len[s];
+  }
+  for (int s = nseg; s < kMaxSeg; ++s) { sa.dst[s] = nullptr; sa.len[s] = 0; sa.nsrc[s] = 0; sa.first[s + 1] = sa.first[nseg]; }
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(cdiv(sa.first[nseg], 64)), dim3(1024), 0, (hipStream_t)stream, ws, nrow,
+                     row_stride, sa, nseg, accumulate);
+  AVDF_CHECK_LAUNCH("reduce_segments");
+  return AVDF_OK;
+}

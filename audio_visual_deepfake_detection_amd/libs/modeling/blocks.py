@@ -171,6 +171,37 @@ class _MHCABase(nn.Module):
         y, out_mask = conv(x, mask)
         return ops.conv1d(norm(y), proj.weight, proj.bias), out_mask
 
+    def attend_prenorm(self, xs, lns, masks):
+        """Block entry: pre-LayerNorms `lns` (ln1 x3 | lnq, lnk, lnv) + attention on raw inputs `xs`.  When the
+        three branches share length and mask (every call site of the shipped backbones) the LN -> depthwise conv
+        -> LN chains of q, k, v run as ONE fused launch (ops.qkv_chain); otherwise the per-op path."""
+        x_q, x_k, x_v = xs
+        C = x_q.shape[-1]
+        same_mask = all(m is masks[0] or (m.data_ptr() == masks[0].data_ptr() and m.shape == masks[0].shape)
+                        for m in masks[1:])
+        if (ops.FUSE_QKV_CHAIN and C <= 256 and x_k.shape == x_q.shape and x_v.shape == x_q.shape and same_mask
+                and all(ln.affine for ln in lns) and len({ln.eps for ln in lns}) == 1
+                and self.query_norm.eps == lns[0].eps and x_q.shape[1] % self.n_kv_stride == 0):
+            out_mask = downsample_mask(masks[0], self.n_kv_stride)
+            norms = (self.query_norm, self.key_norm, self.value_norm)
+            yq, yk, yv = ops.qkv_chain(
+                xs, [(ln.weight, ln.bias) for ln in lns],
+                [self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight],
+                [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps)
+            q = ops.conv1d(yq, self.query.weight, self.query.bias)
+            k = ops.conv1d(yk, self.key.weight, self.key.bias)
+            v = ops.conv1d(yv, self.value.weight, self.value.bias)
+            return self._core(q, k, v, out_mask, out_mask)
+        return self._attend(lns[0](x_q), masks[0], lns[1](x_k), masks[1], lns[2](x_v), masks[2])
+
+    def _core(self, q, k, v, qx_mask, kv_mask):
+        if self.window_size > 1:
+            out = ops.local_attention(q, k, v, kv_mask, self.n_head, self.window_size)
+        else:
+            out = ops.global_attention(q, k, v, kv_mask, self.n_head)
+        out = ops.conv1d(out, self.proj.weight, self.proj.bias, qx_mask)
+        return out, qx_mask
+
     def _attend(self, x_q, mask_q, x_k, mask_k, x_v, mask_v):
         if ops.BRANCH_STREAMS and x_q.is_cuda:
             # the q / k / v chains (depthwise conv -> LayerNorm -> 1x1 projection) are independent and each is
@@ -194,12 +225,7 @@ class _MHCABase(nn.Module):
             q, qx_mask = self._branch(self.query_conv, self.query_norm, self.query, x_q, mask_q)
             k, kv_mask = self._branch(self.key_conv, self.key_norm, self.key, x_k, mask_k)
             v, _ = self._branch(self.value_conv, self.value_norm, self.value, x_v, mask_v)
-        if self.window_size > 1:
-            out = ops.local_attention(q, k, v, kv_mask, self.n_head, self.window_size)
-        else:
-            out = ops.global_attention(q, k, v, kv_mask, self.n_head)
-        out = ops.conv1d(out, self.proj.weight, self.proj.bias, qx_mask)
-        return out, qx_mask
+        return self._core(q, k, v, qx_mask, kv_mask)
 
 
 class MaskedMHCA(_MHCABase):
@@ -300,7 +326,7 @@ class TransformerBlock(_BlockBase):
 
     def forward(self, x, mask, pos_embd=None):
         assert pos_embd is None
-        out, out_mask = self.attn(self.ln1(x), mask)
+        out, out_mask = self.attn.attend_prenorm((x, x, x), (self.ln1, self.ln1, self.ln1), (mask, mask, mask))
         return self._residual_mlp(x, out, out_mask), out_mask
 
 
@@ -327,7 +353,7 @@ class MutilModelTransformerBlock(_BlockBase):
 
     def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None, pos_embd=None):
         assert pos_embd is None
-        out, out_mask = self.attn(self.lnq(x_q), mask_q, self.lnk(x_k), mask_k, self.lnv(x_v), mask_v)
+        out, out_mask = self.attn.attend_prenorm((x_q, x_k, x_v), (self.lnq, self.lnk, self.lnv), (mask_q, mask_k, mask_v))
         return self._residual_mlp(x_q, out, out_mask), out_mask
 
 

@@ -7,11 +7,14 @@ eager/aten fallback -- a CPU tensor or a missing library raises.
 Layout: activations time-major [B, T, C] fp32; masks fp32 [B, T]; weights in the reference
 layouts (Conv1d [Cout, Cin/groups, K], LayerNorm [1, C, 1], ...).
 """
+import ctypes
+
 import torch
 
 from ._lib import lib, check
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_LEAKY = 0, 1, 2, 3
+FUSE_QKV_CHAIN = True      # LN -> depthwise conv -> LN of q, k, v as one fused launch (blocks._MHCABase.attend_prenorm)
 
 # fork/join of independent branches on side streams (blocks._MHCABase._attend); off by default
 BRANCH_STREAMS = False
@@ -313,6 +316,107 @@ class LayerNormFn(torch.autograd.Function):
 
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, pe=None, mask=None):
     return LayerNormFn.apply(x, gamma, beta, eps, relu, pe, mask)
+
+
+# --------------------------------------------------------------------------------------------
+# fused q/k/v input chains: LN -> depthwise k3 (stride s) * mask -> LN, three branches per launch
+# --------------------------------------------------------------------------------------------
+def _ptr_table(ts):
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+class QkvChainFn(torch.autograd.Function):
+    """args: x[3], (gamma_a, beta_a)[3], w[3], (gamma_b, beta_b)[3], mask_out, stride, eps -> y[3].
+    Inputs / parameters of different branches may be the same tensor (TransformerBlock: one x and one ln1)."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, gaq, baq, gak, bak, gav, bav, wq, wk, wv, gbq, bbq, gbk, bbk, gbv, bbv, mask, stride,
+                eps):
+        xs = [_c(xq), _c(xk), _c(xv)]
+        ga, ba = [gaq, gak, gav], [baq, bak, bav]
+        ws_, gb, bb = [wq, wk, wv], [gbq, gbk, gbv], [bbq, bbk, bbv]
+        ctx.main = [[_main_grad(t) for t in grp] for grp in (ga, ba, ws_, gb, bb)]
+        ctx.pshapes = [[t.shape for t in grp] for grp in (ga, ba, ws_, gb, bb)]
+        flat = lambda grp: [t.contiguous().view(-1) for t in grp]
+        ga, ba, ws_, gb, bb = flat(ga), flat(ba), flat(ws_), flat(gb), flat(bb)
+        mask = _c(mask)
+        B, Tin, C = xs[0].shape
+        assert xs[1].shape == xs[0].shape and xs[2].shape == xs[0].shape
+        Tout = (Tin - 1) // stride + 1
+        dev = xs[0].device
+        u = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
+        y = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
+        sa = torch.empty((3, 2, B * Tin), dtype=torch.float32, device=dev)
+        sb = torch.empty((3, 2, B * Tout), dtype=torch.float32, device=dev)
+        for t in xs + ga + ba + ws_ + gb + bb:
+            _p(t)
+        check(lib.avdf_chain_fwd(_ptr_table(xs), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_), _ptr_table(gb),
+                                 _ptr_table(bb), _p(mask), _ptr_table(u), _ptr_table(y), _ptr_table([sa[0], sa[1], sa[2]]),
+                                 _ptr_table([sb[0], sb[1], sb[2]]), B, Tin, Tout, C, stride, eps, _stream()), "chain_fwd")
+        ctx.save_for_backward(*xs, *ga, *ba, *ws_, *gb, mask, *u, sa, sb)
+        ctx.cfg = (B, Tin, Tout, C, stride)
+        ctx.x_same = [xs[i + 1].data_ptr() == xs[i].data_ptr() for i in range(2)]
+        return tuple(y)
+
+    @staticmethod
+    def backward(ctx, dyq, dyk, dyv):
+        sv = ctx.saved_tensors
+        xs, ga, ba, ws_, gb = list(sv[0:3]), list(sv[3:6]), list(sv[6:9]), list(sv[9:12]), list(sv[12:15])
+        mask, u, sa, sb = sv[15], list(sv[16:19]), sv[19], sv[20]
+        B, Tin, Tout, C, stride = ctx.cfg
+        dev = xs[0].device
+        dys = [torch.zeros((B, Tout, C), dtype=torch.float32, device=dev) if d is None else d.contiguous()
+               for d in (dyq, dyk, dyv)]
+        # branches whose input is the same tensor are summed in the kernel; the sum is stored by the group's last branch
+        store = [not ctx.x_same[0], not ctx.x_same[1], True]
+        dx = [torch.empty((B, Tin, C), dtype=torch.float32, device=dev) if st else None for st in store]
+        store_mask = sum(1 << i for i, st in enumerate(store) if st)
+        wsb = _ws(lib.avdf_chain_bwd_ws(B, Tin, C), xs[0])
+        check(lib.avdf_chain_bwd(_ptr_table(dys), _ptr_table(u), _ptr_table([sb[0], sb[1], sb[2]]), _ptr_table(xs),
+                                 _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_),
+                                 _ptr_table(gb), _p(mask), _ptr_table(dx), store_mask, _p(wsb), B, Tin, Tout, C, stride,
+                                 _stream()), "chain_bwd")
+        # parameter gradients: one segmented reduction over the workgroups' rows; sources of a parameter shared by
+        # several branches are summed there
+        mains = ctx.main
+        acc = all(m is not None for grp in mains for m in grp)
+        slot = {0: 0, 1: C, 2: 2 * C, 3: 5 * C, 4: 6 * C}
+        seg_dst, seg_len, seg_src, grads = [], [], [], [[None] * 3 for _ in range(5)]
+        params = (ga, ba, ws_, gb, sv[12:15])      # beta_b is not saved (not needed); its identity follows gamma_b
+        for kind in range(5):
+            seen = {}
+            for br in range(3):
+                key = params[kind][br].data_ptr() if kind != 4 else ("bb", params[3][br].data_ptr())
+                off = br * 7 * C + slot[kind]
+                if key in seen:
+                    seg_src[seen[key]].append(off)
+                    continue
+                n = 3 * C if kind == 2 else C
+                if acc:
+                    dst = mains[kind][br].view(-1)
+                else:
+                    dst = torch.empty(n, dtype=torch.float32, device=dev)
+                    grads[kind][br] = dst.view(ctx.pshapes[kind][br])
+                seen[key] = len(seg_dst)
+                seg_dst.append(dst)
+                seg_len.append(n)
+                seg_src.append([off])
+        nseg = len(seg_dst)
+        lens = (ctypes.c_int * nseg)(*seg_len)
+        nsrc = (ctypes.c_int * nseg)(*[len(s_) for s_ in seg_src])
+        offs = (ctypes.c_int * (nseg * 3))(*[(s_ + [0, 0, 0])[j] for s_ in seg_src for j in range(3)])
+        check(lib.avdf_reduce_segments(_p(wsb), lib.avdf_chain_bwd_rows(B, Tin), 21 * C, nseg, _ptr_table(seg_dst), lens, nsrc,
+                                       offs, 1 if acc else 0, _stream()), "reduce_segments")
+        g = grads
+        return (dx[0], dx[1], dx[2], g[0][0], g[1][0], g[0][1], g[1][1], g[0][2], g[1][2], g[2][0], g[2][1], g[2][2],
+                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None)
+
+
+def qkv_chain(xs, ln_a, dw, ln_b, mask_out, stride, eps=1e-5):
+    """xs: 3 inputs [B,T,C]; ln_a / ln_b: 3 (gamma, beta) pairs; dw: 3 depthwise weights [C,1,3] -> 3 outputs."""
+    return QkvChainFn.apply(xs[0], xs[1], xs[2], ln_a[0][0], ln_a[0][1], ln_a[1][0], ln_a[1][1], ln_a[2][0], ln_a[2][1],
+                            dw[0], dw[1], dw[2], ln_b[0][0], ln_b[0][1], ln_b[1][0], ln_b[1][1], ln_b[2][0], ln_b[2][1],
+                            mask_out, stride, eps)
 
 
 # --------------------------------------------------------------------------------------------

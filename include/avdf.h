@@ -244,6 +244,32 @@ int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, flo
                           int groups, int K, void* stream);
 int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream);
 
+/* ---- fused q/k/v input chains of the conv-attention blocks ---------------------------------------------
+ * y_i = LN_b,i( dwconv_k3,stride s( LN_a,i(x_i) ) * mask ), i = 0..2 (query / key / value), one launch:
+ * ln1 | lnq,lnk,lnv -> query_conv/key_conv/value_conv -> query_norm/key_norm/value_norm
+ * (libs/modeling/blocks.py:1307-1309, 866-868, 239-262, 931-955, 1166-1173).  Every table has 3 entries
+ * (inputs / parameters may alias).  x_i [B,Tin,C]; mask [B,Tout] or NULL; u_i (conv output, kept for the
+ * backward) and y_i [B,Tout,C]; stats_a_i [2][B*Tin], stats_b_i [2][B*Tout] = (mean, rstd).  C % 4 == 0, C <= 256. */
+int avdf_chain_fwd(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                   const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                   const float* mask, float* const* u, float* const* y, float* const* stats_a,
+                   float* const* stats_b, int B, int Tin, int Tout, int C, int stride, float eps, void* stream);
+/* Backward.  dx_i is written when bit i of store_mask is set and then holds the SUM over the branches since the
+ * previous set bit (branches that share an input: 0b100 = one shared input, 0b101 = x0 | x1==x2, 0b111 = all
+ * distinct).  Parameter partials: ws[avdf_chain_bwd_rows][3][7*C] = per branch dgamma_a, dbeta_a, dw ([C][3]),
+ * dgamma_b, dbeta_b -- fold them with avdf_reduce_segments.                                                */
+int64_t avdf_chain_bwd_ws(int B, int Tin, int C);
+int avdf_chain_bwd_rows(int B, int Tin);
+int avdf_chain_bwd(const float* const* dy, const float* const* u, const float* const* stats_b,
+                   const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                   const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                   const float* mask, float* const* dx, int store_mask, float* ws, int B, int Tin, int Tout,
+                   int C, int stride, void* stream);
+/* dst[s][i] (+)= sum over rows r < nrow and sources j < nsrc[s] of ws[r*row_stride + src_off[s*3+j] + i],
+ * i < len[s]; up to 16 segments per launch (host arrays).                                                   */
+int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,
+                         const int* nsrc, const int* src_off, int accumulate, void* stream);
+
 /* ---- LAV-DF visual encoder (C3D; frozen extractor, forward only) -------------------------------------
  * Reference: video_feature/aligned_video/model/video_encoder.py:27-62 (7x Conv3d 3x3x3 pad 1 + LeakyReLU,
  * MaxPool3d((1,p,p))) and extract_video_features.py:19-37 (/255, tail zero pad, nearest resize to 96x96).

@@ -358,3 +358,53 @@ def test_adamw_ema_kernel(ops):
         close(nsq.sqrt(), gn.view(1), "grad norm")
     close(p, pr.detach(), "adamw params", rtol=1e-5)
     close(ema, ema_ref, "ema", rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused LN -> depthwise k3 -> LN chains of q / k / v
+@pytest.mark.parametrize("B,T,C,stride,share", [(2, 96, 256, 1, "all"), (3, 70, 64, 1, "kv"), (2, 64, 32, 2, "none"),
+                                                (8, 768, 256, 1, "all"), (2, 130, 256, 2, "kv"), (1, 33, 8, 1, "all")])
+def test_qkv_chain_matches_torch(ops, B, T, C, stride, share):
+    if stride == 2 and T % 2:
+        T += 1
+    Tout = (T - 1) // stride + 1
+    eps = 1e-5
+    xs = [rnd(B, T, C, seed=1), rnd(B, T, C, seed=2), rnd(B, T, C, seed=3)]
+    if share == "all":
+        xs = [xs[0], xs[0], xs[0]]
+    elif share == "kv":
+        xs = [xs[0], xs[1], xs[1]]
+    npar = 1 if share == "all" else 3
+    la = [(1 + 0.2 * rnd(1, C, 1, seed=10 + i), 0.2 * rnd(1, C, 1, seed=20 + i)) for i in range(npar)]
+    la = [la[0]] * 3 if npar == 1 else la
+    dw = [rnd(C, 1, 3, seed=30 + i, scale=0.5) for i in range(3)]
+    lb = [(1 + 0.2 * rnd(1, C, 1, seed=40 + i), 0.2 * rnd(1, C, 1, seed=50 + i)) for i in range(3)]
+    mask = mk_mask(B, Tout, [Tout - 3 * b for b in range(B)])
+    dys = [rnd(B, Tout, C, seed=60 + i) for i in range(3)]
+
+    # float64 reference
+    uniq = {}
+    def leaf(t):
+        if id(t) not in uniq:
+            uniq[id(t)] = t.clone().requires_grad_(True)
+        return uniq[id(t)]
+    ref_y = []
+    for i in range(3):
+        x, (ga, ba), w, (gb, bb) = leaf(xs[i]), (leaf(la[i][0]), leaf(la[i][1])), leaf(dw[i]), (leaf(lb[i][0]), leaf(lb[i][1]))
+        z = F.layer_norm(x, (C,), ga.view(-1), ba.view(-1), eps)
+        u = F.conv1d(z.transpose(1, 2), w, None, stride, 1, groups=C).transpose(1, 2) * mask[..., None]
+        ref_y.append(F.layer_norm(u, (C,), gb.view(-1), bb.view(-1), eps))
+    sum((y * d).sum() for y, d in zip(ref_y, dys)).backward()
+
+    dmap = {}
+    def dleaf(t):
+        if id(t) not in dmap:
+            dmap[id(t)] = g32(t, True)
+        return dmap[id(t)]
+    got = ops.qkv_chain([dleaf(x) for x in xs], [(dleaf(a), dleaf(b)) for a, b in la], [dleaf(w) for w in dw],
+                        [(dleaf(a), dleaf(b)) for a, b in lb], g32(mask), stride, eps)
+    for i in range(3):
+        close(got[i], ref_y[i], f"chain y[{i}]")
+    sum((y * g32(d)).sum() for y, d in zip(got, dys)).backward()
+    for key, t64 in uniq.items():
+        close(dmap[key].grad, t64.grad, f"chain grad of tensor shape {tuple(t64.shape)}", rtol=5e-5)
