@@ -130,14 +130,27 @@ __device__ __forceinline__ void tile_epilogue(floatx16 (&acc)[MI * NI], float* s
   }
 }
 
+// Up to 3 same-shape problems per launch (the q / k / v projections of an attention block): the exp10 GEMMs are
+// latency-bound (~9 us floor per launch at K = 256), so one 3x larger launch costs about as much as one small one.
+struct FwdPtrs { const float* x[3]; const float* w[3]; const float* bias[3]; const float* mask[3]; float* y[3]; float* ypre[3]; };
+struct DgradPtrs { const float* dy[3]; const float* w[3]; const float* mask[3]; const float* ypre[3]; float* dx[3]; };
+struct WgradPtrs { const float* dy[3]; const float* x[3]; const float* mask[3]; const float* ypre[3]; float* out[3]; float* dbias[3]; };
+template <class T>
+__device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0] : (p == 1 ? a[1] : a[2]); }
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
 __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-    const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ ypre,
-    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy) {
+    FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy) {
+  const int prob = blockIdx.z;
+  const float* __restrict__ x = pick3(ptrs.x, prob);
+  const float* __restrict__ w = pick3(ptrs.w, prob);
+  const float* __restrict__ bias = pick3(ptrs.bias, prob);
+  const float* __restrict__ mask = pick3(ptrs.mask, prob);
+  float* __restrict__ y = pick3(ptrs.y, prob);
+  float* __restrict__ ypre = pick3(ptrs.ypre, prob);
   // P = left zero-padding (K/2 for the "same" convs of the model, 0 for the wav2vec2 feature extractor);
   // ldx / ldw / ldy = row strides of x, w and y in floats (sub-matrix views: attention heads, weight slices)
   static_assert(WM * WN == 4, "4 waves per K-group");
@@ -286,9 +299,13 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
 __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
-    const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ mask,
-    const float* __restrict__ ypre, float* __restrict__ dx,
-    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
+    DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
+  const int prob = blockIdx.z;
+  const float* __restrict__ dy = pick3(ptrs.dy, prob);
+  const float* __restrict__ w = pick3(ptrs.w, prob);
+  const float* __restrict__ mask = pick3(ptrs.mask, prob);
+  const float* __restrict__ ypre = pick3(ptrs.ypre, prob);
+  float* __restrict__ dx = pick3(ptrs.dx, prob);
   static_assert(WM * WN == 4, "4 waves per K-group");
   static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
   constexpr int NT = 256 * KG;
@@ -432,10 +449,15 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
 // ------------------------------------------------------------------------------------------
 template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC>
 __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mask,
-    const float* __restrict__ ypre, float* __restrict__ out, float* __restrict__ dbias,
-    int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip, int tilesPerSplit,
-    int accumulate) {
+    WgradPtrs ptrs, int mtiles, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip,
+    int tilesPerSplit, int accumulate) {
+  const int prob = blockIdx.x / mtiles;
+  const float* __restrict__ dy = pick3(ptrs.dy, prob);
+  const float* __restrict__ x = pick3(ptrs.x, prob);
+  const float* __restrict__ mask = pick3(ptrs.mask, prob);
+  const float* __restrict__ ypre = pick3(ptrs.ypre, prob);
+  float* __restrict__ out = pick3(ptrs.out, prob);
+  float* __restrict__ dbias = pick3(ptrs.dbias, prob);
   static_assert(WM * WN == 4, "4 waves per K-group");
   static_assert(KT % (2 * KG) == 0, "token tile must split evenly into pairs per group");
   constexpr int NT = 256 * KG;
@@ -455,7 +477,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
   const int kg = wid >> 2, w4 = wid & 3;
   const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * BM, c0 = blockIdx.y * BN;
+  const int n0 = (blockIdx.x % mtiles) * BM, c0 = blockIdx.y * BN;
   const int gbeg = blockIdx.z * tilesPerSplit;
   int gend = gbeg + tilesPerSplit;
   const int gtot = B * tilesPerClip;
@@ -673,7 +695,7 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false) {
 }
 
 struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles, kg; bool small; };
-inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
+inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K, int nprob = 1) {
   WgradPlan p;
   p.small = ((int64_t)Cout * Cin * K <= 512 * 1024);
   const int KT = p.small ? 128 : 64;           // tokens per K-tile (must match the launch below)
@@ -682,7 +704,7 @@ inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K) {
   p.ctiles = cdiv(Cin, 64);
   p.tilesPerClip = cdiv(Tout, KT);
   const int total = B * p.tilesPerClip;
-  const int tiles = p.mtiles * p.ctiles;
+  const int tiles = p.mtiles * p.ctiles * nprob;
   p.kg = p.small ? (tiles >= 256 ? 1 : (tiles >= 64 ? 2 : 4)) : (tiles >= 256 ? 1 : 2);
   if (K == 3 && p.kg > 2) p.kg = 2;            // 3 accumulator sets per wave: keep the LDS reduction small
   int want = cdiv(1024, tiles * p.kg);
@@ -730,18 +752,16 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
     default: L(KS_, S_, KC3_, 1, 4, 1, 1, 4); break;                               \
   }
 
-static int conv1d_fwd_launch(const float* x, const float* w, const float* bias, const float* mask, float* y,
-                             float* ypre, int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int pad,
-                             int ldx, int ldw, int ldy, int act, hipStream_t st) {
-  const TilePlan plan = pick_tile(B, Tout, Cout);
+static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
+                             int stride, int pad, int ldx, int ldw, int ldy, int act, hipStream_t st) {
+  const TilePlan plan = pick_tile(B * nprob, Tout, Cout);
 #define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
   do {                                                                                                  \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
     const int tilesT = cdiv(Tout, BM_);                                                                 \
-    dim3 grid(B * tilesT, cdiv(Cout, BN_));                                                             \
+    dim3 grid(B * tilesT, cdiv(Cout, BN_), nprob);                                                      \
     hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
-                       0, st, x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
-                       ldx, ldw, ldy);                                                                  \
+                       0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy);          \
   } while (0)
   if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_FWD) }
   else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_FWD) }
@@ -750,6 +770,12 @@ static int conv1d_fwd_launch(const float* x, const float* w, const float* bias, 
 #undef LAUNCH_FWD
   AVDF_CHECK_LAUNCH("conv1d_fwd");
   return AVDF_OK;
+}
+
+static FwdPtrs fwd_ptrs1(const float* x, const float* w, const float* bias, const float* mask, float* y, float* ypre) {
+  FwdPtrs g;
+  for (int i = 0; i < 3; ++i) { g.x[i] = x; g.w[i] = w; g.bias[i] = bias; g.mask[i] = mask; g.y[i] = y; g.ypre[i] = ypre; }
+  return g;
 }
 
 extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const float* mask,
@@ -762,8 +788,28 @@ extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias
   AVDF_REQUIRE(Cin % 4 == 0, "conv1d_fwd: Cin %% 4 != 0 (Cin=%d)", Cin);
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd: Tout=%d inconsistent with Tin=%d K=%d s=%d", Tout, Tin, K, stride);
   AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd: x/w must be 16-byte aligned");
-  return conv1d_fwd_launch(x, w, bias, mask, y, ypre, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin, Cin * K, Cout,
-                           act, (hipStream_t)stream);
+  return conv1d_fwd_launch(fwd_ptrs1(x, w, bias, mask, y, ypre), 1, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin,
+                           Cin * K, Cout, act, (hipStream_t)stream);
+}
+
+// Same-shape problems in one launch (n <= 3): q / k / v projections.  Tables of n device pointers; bias / mask /
+// ypre tables may be NULL (= absent for every problem) or hold NULL entries.
+extern "C" int avdf_conv1d_fwd_grouped(int n, const float* const* x, const float* const* w, const float* const* bias,
+                                       const float* const* mask, float* const* y, float* const* ypre, int B, int Tin,
+                                       int Cin, int Tout, int Cout, int K, int stride, int act, void* stream) {
+  AVDF_REQUIRE(n >= 1 && n <= 3 && x && w && y, "conv1d_fwd_grouped: 1..3 problems, non-null tables");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_fwd_grouped: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_fwd_grouped: unsupported K/stride");
+  AVDF_REQUIRE(Cin % 4 == 0, "conv1d_fwd_grouped: Cin %% 4 != 0 (Cin=%d)", Cin);
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd_grouped: Tout inconsistent");
+  FwdPtrs g;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < n ? i : 0;
+    AVDF_REQUIRE(x[j] && w[j] && y[j] && aligned16(x[j]) && aligned16(w[j]), "conv1d_fwd_grouped: null / misaligned problem %d", j);
+    g.x[i] = x[j]; g.w[i] = w[j]; g.y[i] = y[j];
+    g.bias[i] = bias ? bias[j] : nullptr; g.mask[i] = mask ? mask[j] : nullptr; g.ypre[i] = ypre ? ypre[j] : nullptr;
+  }
+  return conv1d_fwd_launch(g, n, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin, Cin * K, Cout, act, (hipStream_t)stream);
 }
 
 // General forward form used by the frozen extractors: explicit zero-padding `pad` (0 = "valid" conv of the
@@ -781,28 +827,20 @@ extern "C" int avdf_conv1d_fwd_ex(const float* x, const float* w, const float* b
                "conv1d_fwd_ex: Cin/ldx/ldw must be multiples of 4 and cover the operands");
   AVDF_REQUIRE(Tout == (Tin + 2 * pad - K) / stride + 1, "conv1d_fwd_ex: Tout=%d inconsistent", Tout);
   AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd_ex: x/w must be 16-byte aligned");
-  return conv1d_fwd_launch(x, w, bias, nullptr, y, nullptr, B, Tin, Cin, Tout, Cout, K, stride, pad, ldx, ldw, ldy,
-                           act, (hipStream_t)stream);
+  return conv1d_fwd_launch(fwd_ptrs1(x, w, bias, nullptr, y, nullptr), 1, B, Tin, Cin, Tout, Cout, K, stride, pad, ldx,
+                           ldw, ldy, act, (hipStream_t)stream);
 }
 
-extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,
-                                    float* dx, int B, int Tin, int Cin, int Tout, int Cout,
-                                    int K, int stride, int act, void* stream) {
-  AVDF_REQUIRE(dy && w && dx, "conv1d_bwd_data: null pointer");
-  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_bwd_data: bad dims");
-  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_bwd_data: unsupported K/stride");
-  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_data: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
-  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_data: Tout inconsistent");
-  AVDF_REQUIRE(aligned16(dy) && aligned16(w) && (!ypre || aligned16(ypre)), "conv1d_bwd_data: 16-byte alignment");
-  hipStream_t st = (hipStream_t)stream;
-  const TilePlan plan = pick_tile(B, Tin, Cin, true);
+static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
+                               int stride, int act, hipStream_t st) {
+  const TilePlan plan = pick_tile(B * nprob, Tin, Cin, true);
 #define LAUNCH_DG(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                                  \
   do {                                                                                                    \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                             \
     const int tilesT = cdiv(Tin, BM_);                                                                    \
-    dim3 grid(B * tilesT, cdiv(Cin, BN_));                                                                \
+    dim3 grid(B * tilesT, cdiv(Cin, BN_), nprob);                                                         \
     hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
-                       0, st, dy, w, mask, ypre, dx, B, Tin, Cin, Tout, Cout, act, tilesT);               \
+                       0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);                                \
   } while (0)
   if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_DG) }
   else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_DG) }
@@ -812,10 +850,73 @@ extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float
   return AVDF_OK;
 }
 
+extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,
+                                    float* dx, int B, int Tin, int Cin, int Tout, int Cout,
+                                    int K, int stride, int act, void* stream) {
+  const float* dys[1] = {dy};
+  const float* ws_[1] = {w};
+  const float* ms[1] = {mask};
+  const float* ps[1] = {ypre};
+  float* dxs[1] = {dx};
+  return avdf_conv1d_bwd_data_grouped(1, dys, ws_, ms, ps, dxs, B, Tin, Cin, Tout, Cout, K, stride, act, stream);
+}
+
+extern "C" int avdf_conv1d_bwd_data_grouped(int n, const float* const* dy, const float* const* w,
+                                            const float* const* mask, const float* const* ypre, float* const* dx,
+                                            int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int act,
+                                            void* stream) {
+  AVDF_REQUIRE(n >= 1 && n <= 3 && dy && w && dx, "conv1d_bwd_data: 1..3 problems, non-null tables");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_bwd_data: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_bwd_data: unsupported K/stride");
+  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_data: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_data: Tout inconsistent");
+  DgradPtrs g;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < n ? i : 0;
+    AVDF_REQUIRE(dy[j] && w[j] && dx[j], "conv1d_bwd_data: null pointer (problem %d)", j);
+    g.dy[i] = dy[j]; g.w[i] = w[j]; g.dx[i] = dx[j];
+    g.mask[i] = mask ? mask[j] : nullptr; g.ypre[i] = ypre ? ypre[j] : nullptr;
+    AVDF_REQUIRE(aligned16(g.dy[i]) && aligned16(g.w[i]) && aligned16(g.ypre[i]), "conv1d_bwd_data: 16-byte alignment");
+  }
+  return conv1d_dgrad_launch(g, n, B, Tin, Cin, Tout, Cout, K, stride, act, (hipStream_t)stream);
+}
+
 extern "C" int64_t avdf_conv1d_bwd_weight_ws(int B, int Tout, int Cin, int Cout, int K) {
   const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
   const int64_t slab = (p.splits > 1) ? (int64_t)p.splits * Cout * Cin * K : 0;
   return slab + (int64_t)kColsumBlocks * Cout;
+}
+
+// one launch for `nprob` same-shape problems; `target[i]` = dw (atomic / unsplit) or the slab workspace
+static int conv1d_wgrad_launch(const WgradPtrs& ptrs, int nprob, const WgradPlan& p, int B, int Tin, int Cin, int Tout,
+                               int Cout, int K, int stride, int act, int accumulate, bool atomic, hipStream_t st) {
+#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_)                                                        \
+  do {                                                                                                          \
+    if (atomic)                                                                                                 \
+      hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, true>),                      \
+                         dim3(p.mtiles * nprob, p.ctiles, p.splits), dim3(256 * KG_), 0, st, ptrs, p.mtiles, B, \
+                         Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);               \
+    else                                                                                                        \
+      hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, false>),                     \
+                         dim3(p.mtiles * nprob, p.ctiles, p.splits), dim3(256 * KG_), 0, st, ptrs, p.mtiles, B, \
+                         Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);               \
+  } while (0)
+#define LAUNCH_WG_KG(KS_, S_)                                                   \
+  if (p.small) {                                                                \
+    if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 2);                      \
+    else LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 1);                                \
+  } else {                                                                      \
+    if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 2, 1, 64, 2);                       \
+    else LAUNCH_WG(KS_, S_, 2, 2, 2, 1, 64, 1);                                 \
+  }
+  if (K == 3 && stride == 1) { LAUNCH_WG_KG(3, 1) }
+  else if (K == 3 && stride == 2) { LAUNCH_WG_KG(3, 2) }
+  else if (p.small && p.kg == 4) { LAUNCH_WG(1, 1, 2, 2, 1, 1, 128, 4); }
+  else { LAUNCH_WG_KG(1, 1) }
+#undef LAUNCH_WG_KG
+#undef LAUNCH_WG
+  AVDF_CHECK_LAUNCH("conv1d_bwd_weight");
+  return AVDF_OK;
 }
 
 extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const float* mask, const float* ypre,
@@ -834,43 +935,54 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   // atomics-based wgrad.  accumulate == 0: deterministic slabs + reducer.
   const bool atomic = accumulate != 0;
   float* target = (p.splits > 1 && !atomic) ? ws : dw;
-#define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_)                                                        \
-  do {                                                                                                          \
-    if (atomic)                                                                                                 \
-      hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, true>),                      \
-                         dim3(p.mtiles, p.ctiles, p.splits), dim3(256 * KG_), 0, st, dy, x, mask, ypre, target, \
-                         dbias, B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);     \
-    else                                                                                                        \
-      hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, false>),                     \
-                         dim3(p.mtiles, p.ctiles, p.splits), dim3(256 * KG_), 0, st, dy, x, mask, ypre, target, \
-                         dbias, B, Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);     \
-  } while (0)
-#define LAUNCH_WG_KG(KS_, S_)                                                   \
-  if (p.small) {                                                                \
-    if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 2);                      \
-    else LAUNCH_WG(KS_, S_, 2, 2, 1, 1, 128, 1);                                \
-  } else {                                                                      \
-    if (p.kg == 2) LAUNCH_WG(KS_, S_, 2, 2, 2, 1, 64, 2);                       \
-    else LAUNCH_WG(KS_, S_, 2, 2, 2, 1, 64, 1);                                 \
-  }
-  if (K == 3 && stride == 1) { LAUNCH_WG_KG(3, 1) }
-  else if (K == 3 && stride == 2) { LAUNCH_WG_KG(3, 2) }
-  else if (p.small && p.kg == 4) { LAUNCH_WG(1, 1, 2, 2, 1, 1, 128, 4); }
-  else { LAUNCH_WG_KG(1, 1) }
-#undef LAUNCH_WG_KG
-#undef LAUNCH_WG
-  AVDF_CHECK_LAUNCH("conv1d_bwd_weight");
+  WgradPtrs g;
+  for (int i = 0; i < 3; ++i) { g.dy[i] = dy; g.x[i] = x; g.mask[i] = mask; g.ypre[i] = ypre; g.out[i] = target; g.dbias[i] = dbias; }
+  int rc = conv1d_wgrad_launch(g, 1, p, B, Tin, Cin, Tout, Cout, K, stride, act, accumulate, atomic, st);
+  if (rc) return rc;
   if (atomic) return AVDF_OK;
   if (p.splits > 1) {
-    int rc = avdf_reduce_slabs(ws, dw, p.splits, (int64_t)Cout * Cin * K, accumulate, st);
+    rc = avdf_reduce_slabs(ws, dw, p.splits, (int64_t)Cout * Cin * K, accumulate, st);
     if (rc) return rc;
   }
   if (dbias) {
     float* part = ws + (p.splits > 1 ? (size_t)p.splits * Cout * Cin * K : 0);
     hipLaunchKernelGGL(colsum_kernel, dim3(kColsumBlocks), dim3(256), 0, st, dy, mask, ypre, part, B * Tout, Cout, act);
     AVDF_CHECK_LAUNCH("colsum");
-    int rc = avdf_reduce_slabs(part, dbias, kColsumBlocks, Cout, accumulate, st);
+    rc = avdf_reduce_slabs(part, dbias, kColsumBlocks, Cout, accumulate, st);
     if (rc) return rc;
   }
   return AVDF_OK;
+}
+
+// n same-shape problems.  accumulate != 0: ONE launch (atomics into dw[i] / dbias[i]); accumulate == 0: the
+// deterministic per-problem path, `ws` sized n * avdf_conv1d_bwd_weight_ws(...).
+extern "C" int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* const* x,
+                                              const float* const* mask, const float* const* ypre, float* const* dw,
+                                              float* const* dbias, float* ws, int B, int Tin, int Cin, int Tout,
+                                              int Cout, int K, int stride, int act, int accumulate, void* stream) {
+  AVDF_REQUIRE(n >= 1 && n <= 3 && dy && x && dw && ws, "conv1d_bwd_weight_grouped: 1..3 problems, non-null tables");
+  if (!accumulate) {
+    const int64_t per = avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K);
+    for (int i = 0; i < n; ++i) {
+      int rc = avdf_conv1d_bwd_weight(dy[i], x[i], mask ? mask[i] : nullptr, ypre ? ypre[i] : nullptr, dw[i],
+                                      dbias ? dbias[i] : nullptr, ws + (size_t)i * ((per + 3) / 4 * 4), B, Tin, Cin, Tout,
+                                      Cout, K, stride, act, 0, stream);
+      if (rc) return rc;
+    }
+    return AVDF_OK;
+  }
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_bwd_weight_grouped: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_bwd_weight_grouped: unsupported K/stride");
+  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_weight_grouped: Cin,Cout must be multiples of 4");
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_weight_grouped: Tout inconsistent");
+  WgradPtrs g;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < n ? i : 0;
+    AVDF_REQUIRE(dy[j] && x[j] && dw[j], "conv1d_bwd_weight_grouped: null pointer (problem %d)", j);
+    g.dy[i] = dy[j]; g.x[i] = x[j]; g.out[i] = dw[j];
+    g.mask[i] = mask ? mask[j] : nullptr; g.ypre[i] = ypre ? ypre[j] : nullptr; g.dbias[i] = dbias ? dbias[j] : nullptr;
+    AVDF_REQUIRE(aligned16(g.dy[i]) && aligned16(g.x[i]) && aligned16(g.ypre[i]), "conv1d_bwd_weight_grouped: 16-byte alignment");
+  }
+  WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, n);
+  return conv1d_wgrad_launch(g, n, p, B, Tin, Cin, Tout, Cout, K, stride, act, accumulate, true, (hipStream_t)stream);
 }

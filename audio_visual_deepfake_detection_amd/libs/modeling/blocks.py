@@ -188,9 +188,8 @@ class _MHCABase(nn.Module):
                 xs, [(ln.weight, ln.bias) for ln in lns],
                 [self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight],
                 [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps)
-            q = ops.conv1d(yq, self.query.weight, self.query.bias)
-            k = ops.conv1d(yk, self.key.weight, self.key.bias)
-            v = ops.conv1d(yv, self.value.weight, self.value.bias)
+            q, k, v = ops.conv1d_group3((yq, yk, yv), (self.query.weight, self.key.weight, self.value.weight),
+                                        (self.query.bias, self.key.bias, self.value.bias))
             return self._core(q, k, v, out_mask, out_mask)
         return self._attend(lns[0](x_q), masks[0], lns[1](x_k), masks[1], lns[2](x_v), masks[2])
 

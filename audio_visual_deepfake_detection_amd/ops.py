@@ -93,6 +93,11 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+def _ptr_table(ts):
+    """Host array of device pointers (the grouped C-ABI entries take `const float* const*` tables)."""
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
 def _ws(n, like):
     return torch.empty(max(int(n), 1), dtype=torch.float32, device=like.device)
 
@@ -162,6 +167,68 @@ class Conv1dFn(torch.autograd.Function):
 
 def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE):
     return Conv1dFn.apply(x, w, bias, mask, stride, act)
+
+
+class Conv1dGroup3Fn(torch.autograd.Function):
+    """Three same-shape dense convs (no mask, no activation) as ONE launch each for forward, dgrad and wgrad:
+    the q / k / v 1x1 projections (blocks.py:1176-1178, 734-736)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, x2, w0, w1, w2, b0, b1, b2):
+        ws0, bs0 = [w0, w1, w2], [b0, b1, b2]
+        xs, ws_, bs = [_c(t) for t in (x0, x1, x2)], [_c(t) for t in ws0], [_c(t) for t in bs0]
+        B, T, Cin = xs[0].shape
+        Cout, Cin_w, K = ws_[0].shape
+        assert Cin_w == Cin and all(t.shape == xs[0].shape for t in xs) and all(t.shape == ws_[0].shape for t in ws_)
+        has_bias = bs[0] is not None
+        assert all((b is not None) == has_bias for b in bs)
+        ys = [torch.empty((B, T, Cout), dtype=torch.float32, device=xs[0].device) for _ in range(3)]
+        for t in xs + ws_ + ([b for b in bs] if has_bias else []):
+            _p(t)
+        fl = 3 * 2.0 * B * T * Cout * Cin * K
+        _timed(_conv_tag("fwd3", K, 1, 3 * B, T, Cout), fl, lambda: check(
+            lib.avdf_conv1d_fwd_grouped(3, _ptr_table(xs), _ptr_table(ws_), _ptr_table(bs) if has_bias else None, None,
+                                        _ptr_table(ys), None, B, T, Cin, T, Cout, K, 1, ACT_NONE, _stream()),
+            "conv1d_fwd_grouped"))
+        ctx.save_for_backward(*xs, *ws_)
+        ctx.cfg = (B, T, Cin, Cout, K, has_bias)
+        ctx.main = ([_main_grad(t) for t in ws0], [_main_grad(t) for t in bs0])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        sv = ctx.saved_tensors
+        xs, ws_ = list(sv[0:3]), list(sv[3:6])
+        B, T, Cin, Cout, K, has_bias = ctx.cfg
+        dev = xs[0].device
+        dys = [torch.zeros((B, T, Cout), dtype=torch.float32, device=dev) if d is None else d.contiguous() for d in (d0, d1, d2)]
+        st = _stream()
+        fl = 3 * 2.0 * B * T * Cout * Cin * K
+        dxs = [None] * 3
+        if any(ctx.needs_input_grad[0:3]):
+            dxs = [torch.empty_like(x) for x in xs]
+            _timed(_conv_tag("dgrad3", K, 1, 3 * B, T, Cin), fl, lambda: check(
+                lib.avdf_conv1d_bwd_data_grouped(3, _ptr_table(dys), _ptr_table(ws_), None, None, _ptr_table(dxs), B, T, Cin,
+                                                 T, Cout, K, 1, ACT_NONE, st), "conv1d_bwd_data_grouped"))
+        mw, mb = ctx.main
+        acc = 1 if all(m is not None for m in mw) and (not has_bias or all(m is not None for m in mb)) else 0
+        dws = [m.view(ws_[0].shape) for m in mw] if acc else [torch.empty_like(w) for w in ws_]
+        dbs = None
+        if has_bias:
+            dbs = [m.view(Cout) for m in mb] if acc else [torch.empty(Cout, dtype=torch.float32, device=dev) for _ in range(3)]
+        per = (int(lib.avdf_conv1d_bwd_weight_ws(B, T, Cin, Cout, K)) + 3) // 4 * 4
+        wsb = _ws(3 * per, xs[0])
+        _timed(f"conv_wgrad3_k{K}s1+reduce", fl, lambda: check(
+            lib.avdf_conv1d_bwd_weight_grouped(3, _ptr_table(dys), _ptr_table(xs), None, None, _ptr_table(dws),
+                                               _ptr_table(dbs) if has_bias else None, _p(wsb), B, T, Cin, T, Cout, K, 1,
+                                               ACT_NONE, acc, st), "conv1d_bwd_weight_grouped"))
+        if acc:
+            return (*dxs, None, None, None, None, None, None)
+        return (*dxs, *dws, *(dbs if has_bias else [None] * 3))
+
+
+def conv1d_group3(xs, ws, bs):
+    return Conv1dGroup3Fn.apply(xs[0], xs[1], xs[2], ws[0], ws[1], ws[2], bs[0], bs[1], bs[2])
 
 
 class ConvTranspose1dFn(torch.autograd.Function):
@@ -321,10 +388,6 @@ def layernorm(x, gamma, beta, eps=1e-5, relu=False, pe=None, mask=None):
 # --------------------------------------------------------------------------------------------
 # fused q/k/v input chains: LN -> depthwise k3 (stride s) * mask -> LN, three branches per launch
 # --------------------------------------------------------------------------------------------
-def _ptr_table(ts):
-    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
-
-
 class QkvChainFn(torch.autograd.Function):
     """args: x[3], (gamma_a, beta_a)[3], w[3], (gamma_b, beta_b)[3], mask_out, stride, eps -> y[3].
     Inputs / parameters of different branches may be the same tensor (TransformerBlock: one x and one ln1)."""

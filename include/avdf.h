@@ -43,6 +43,21 @@ int avdf_conv1d_fwd(const float* x, const float* w, const float* bias, const flo
                     float* y, float* ypre, int B, int Tin, int Cin, int Tout, int Cout,
                     int K, int stride, int act, void* stream);
 
+/* Up to 3 same-shape problems in one launch (q / k / v projections: blocks.py:1176-1178, 734-736).  Tables of n
+ * device pointers (host arrays); bias / mask / ypre tables may be NULL or hold NULL entries.                  */
+int avdf_conv1d_fwd_grouped(int n, const float* const* x, const float* const* w, const float* const* bias,
+                            const float* const* mask, float* const* y, float* const* ypre, int B, int Tin,
+                            int Cin, int Tout, int Cout, int K, int stride, int act, void* stream);
+int avdf_conv1d_bwd_data_grouped(int n, const float* const* dy, const float* const* w, const float* const* mask,
+                                 const float* const* ypre, float* const* dx, int B, int Tin, int Cin, int Tout,
+                                 int Cout, int K, int stride, int act, void* stream);
+/* accumulate != 0: one launch, float atomics into dw[i] / dbias[i]; accumulate == 0: deterministic per-problem
+ * path, ws sized n * round4(avdf_conv1d_bwd_weight_ws(...)).                                                   */
+int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* const* x, const float* const* mask,
+                                   const float* const* ypre, float* const* dw, float* const* dbias, float* ws,
+                                   int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int act,
+                                   int accumulate, void* stream);
+
 /* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the
  * wav2vec2 feature extractor, fairseq ConvFeatureExtractionModel named at audio_feature/emotion_audio/upstream/
  * models/audio.py:12-17,66-71) and explicit row strides (floats), so x / w / y may be column slices of wider

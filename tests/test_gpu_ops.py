@@ -408,3 +408,30 @@ def test_qkv_chain_matches_torch(ops, B, T, C, stride, share):
     sum((y * g32(d)).sum() for y, d in zip(got, dys)).backward()
     for key, t64 in uniq.items():
         close(dmap[key].grad, t64.grad, f"chain grad of tensor shape {tuple(t64.shape)}", rtol=5e-5)
+
+
+@pytest.mark.parametrize("B,T,C,bias,main", [(2, 96, 64, True, False), (8, 768, 256, True, True), (3, 50, 32, False, False)])
+def test_conv1d_group3_matches_three_convs(ops, B, T, C, bias, main):
+    xs = [rnd(B, T, C, seed=i) for i in range(3)]
+    ws = [rnd(C, C, 1, seed=10 + i, scale=C ** -0.5) for i in range(3)]
+    bs = [rnd(C, seed=20 + i) if bias else None for i in range(3)]
+    dys = [rnd(B, T, C, seed=30 + i) for i in range(3)]
+    x64 = [t.clone().requires_grad_(True) for t in xs]
+    w64 = [t.clone().requires_grad_(True) for t in ws]
+    b64 = [None if t is None else t.clone().requires_grad_(True) for t in bs]
+    ref = [F.conv1d(x.transpose(1, 2), w, b).transpose(1, 2) for x, w, b in zip(x64, w64, b64)]
+    sum((y * d).sum() for y, d in zip(ref, dys)).backward()
+    xd, wd = [g32(t, True) for t in xs], [g32(t, True) for t in ws]
+    bd = [None if t is None else g32(t, True) for t in bs]
+    if main:          # engine path: kernels accumulate straight into `main_grad`
+        for t in wd + [b for b in bd if b is not None]:
+            t.main_grad = torch.zeros_like(t)
+    got = ops.conv1d_group3(xd, wd, bd)
+    for i in range(3):
+        close(got[i], ref[i], f"group3 y[{i}]")
+    sum((y * g32(d)).sum() for y, d in zip(got, dys)).backward()
+    for i in range(3):
+        close(xd[i].grad, x64[i].grad, f"group3 dx[{i}]")
+        close(wd[i].main_grad if main else wd[i].grad, w64[i].grad, f"group3 dw[{i}]", rtol=5e-5)
+        if bias:
+            close(bd[i].main_grad if main else bd[i].grad, b64[i].grad, f"group3 db[{i}]", rtol=5e-5)
