@@ -69,7 +69,10 @@ def _pick_tile(B, T, N):
 
 
 def _conv_tag(kind, K, stride, B, T, N):
-    return f"conv_{kind}_k{K}s{stride}_{('128x128', '64x128', '64x64', '32x128')[_pick_tile(B, T, N)]}"
+    tile = _pick_tile(B, T, N)
+    if kind.startswith("dgrad") and tile == 2:
+        tile = 3                                   # dgrad prefers 32x128 over 64x64 (pick_tile(..., dgrad=true))
+    return f"conv_{kind}_k{K}s{stride}_{('128x128', '64x128', '64x64', '32x128')[tile]}"
 
 
 def _stream():
