@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--branch-streams", action="store_true", help="run the q/k/v chains on three HIP streams")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "e2e"],
+                    help="train (headline), infer (K1 -> fwd -> decode+NMS), e2e (raw PCM + frames -> 3 encoders -> infer)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +144,27 @@ def main():
     torch.manual_seed(1234 + rank)             # rank-offset drop-path / dropout streams
 
     B = args.batch
+    extract = None
+    if args.mode == "e2e":
+        # BASELINE config 5 per-GPU share: raw 16 kHz PCM U(-0.5, 0.5) and 224x224 uint8 frames U{0..255} of 768-frame
+        # clips -> BYOL-A, Emotion2Vec, C3D (random-init weights) -> K1 -> UMMAFormer -> NMS
+        from audio_visual_deepfake_detection_amd.extractors import (LogMelFrontEnd, AudioNTT2020Task6, byola_features,
+                                                                     Emotion2Vec, emotion2vec_features, C3DVideoEncoder,
+                                                                     video_features)
+        torch.manual_seed(7)
+        fe, byola = LogMelFrontEnd().to(dev), AudioNTT2020Task6().to(dev).eval()
+        e2v, c3d = Emotion2Vec().to(dev), C3DVideoEncoder().to(dev)
+        g = torch.Generator(device=dev).manual_seed(3000 + rank)
+        pcm = torch.rand((B, 491520), generator=g, device=dev) - 0.5
+        frames = torch.randint(0, 256, (B, 768, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)
+
+        def extract(eng):
+            for b in range(B):
+                fv = video_features(frames[b], c3d)
+                fa = byola_features(pcm[b], byola, fe)[:STREAMS[1][0]]          # dataset trim (deepfake_video_audio.py:1683)
+                fe_ = emotion2vec_features(pcm[b], e2v)
+                for dst, src in zip(eng.streams[b], (fv, fa, fe_)):
+                    dst.copy_(src)
     if args.mode == "train":
         eng = TrainStep(model, B, STREAMS, lr=cfg["opt"]["learning_rate"] * world,        # train.py:60 LR rule
                         weight_decay=cfg["opt"]["weight_decay"], clip_grad_l2norm=cfg["train_cfg"]["clip_grad_l2norm"],
@@ -157,12 +179,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def one_step():
+        if extract is not None:
+            extract(eng)
         eng.step()
+
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.step()
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -217,14 +244,17 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "AV clips/sec (768-frame) fwd+bwd" if args.mode == "train" else "AV clips/sec (768-frame) inference",
+            "metric": {"train": "AV clips/sec (768-frame) fwd+bwd", "infer": "AV clips/sec (768-frame) inference",
+                       "e2e": "AV clips/sec (768-frame) raw media -> features -> localisation"}[args.mode],
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "exp10 AV-fusion UMMAFormer training step (K1 interp -> fwd -> losses -> bwd -> "
                                    "clip+AdamW+EMA), T=768, C_in=3072 (LAV-DF 256 + BYOL-A 2048 + Emotion2Vec 768), "
                                    "random-init weights" if args.mode == "train" else
-                                   "exp10 AV-fusion UMMAFormer inference (K1 interp -> fwd -> decode+NMS)",
+                                   ("exp10 AV-fusion UMMAFormer inference (K1 interp -> fwd -> decode+NMS)" if args.mode == "infer"
+                                    else "raw PCM (491520 samples) + 768x224x224 u8 frames -> log-mel/BYOL-A + Emotion2Vec + C3D "
+                                         "-> K1 -> exp10 UMMAFormer inference -> decode+NMS, random-init weights"),
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": 768,
                        "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
                        "dead_params_skipped": len(getattr(eng, "dead", []))},
