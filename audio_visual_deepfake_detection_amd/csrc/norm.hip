@@ -254,6 +254,137 @@ extern "C" int avdf_layernorm_fwd(const float* x, const float* gamma, const floa
   return AVDF_OK;
 }
 
+// ---- fused AffineDropPath residual + LayerNorm (TransformerBlock: blocks.py:1311-1313 / 870-872) --------------
+//   out = a*ma[row] + scale[c]*keep[b]*(r*mr[row]);  h = LN(out)*gamma + beta.       One wave per token row.
+template <int NV>
+__global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ ma, const float* __restrict__ r, const float* __restrict__ mr,
+    const float* __restrict__ scale, const float* __restrict__ keep, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ out, float* __restrict__ h, float* __restrict__ mean_o,
+    float* __restrict__ rstd_o, int M, int T, int C, float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wid;
+  if (row >= M) return;
+  const float fa = ma ? ma[row] : 1.f;
+  float fr = keep ? keep[row / T] : 1.f;
+  if (mr) fr *= mr[row];
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      const float4 av = ld4(a + (size_t)row * C + c), rv = ld4(r + (size_t)row * C + c), sc = ld4(scale + c);
+      v[j].x = av.x * fa + rv.x * sc.x * fr; v[j].y = av.y * fa + rv.y * sc.y * fr;
+      v[j].z = av.z * fa + rv.z * sc.z * fr; v[j].w = av.w * fa + rv.w * sc.w * fr;
+      *reinterpret_cast<float4*>(out + (size_t)row * C + c) = v[j];
+      s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) {
+      const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+      q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) {
+      const float4 g = ld4(gamma + c), bb = ld4(beta + c);
+      float4 o;
+      o.x = (v[j].x - mean) * rstd * g.x + bb.x; o.y = (v[j].y - mean) * rstd * g.y + bb.y;
+      o.z = (v[j].z - mean) * rstd * g.z + bb.z; o.w = (v[j].w - mean) * rstd * g.w + bb.w;
+      *reinterpret_cast<float4*>(h + (size_t)row * C + c) = o;
+    }
+  }
+}
+
+// backward: dtot = dout (direct consumer of `out`, may be NULL) + LN'(dh);  da = dtot*ma;  dr = dtot*scale*keep*mr;
+// dscale += sum dtot*r*keep*mr;  dgamma += sum dh*xhat;  dbeta += sum dh.  NW waves, partials folded in LDS, then
+// atomics (accumulate path) or a workspace row [3*C] per workgroup.
+template <int NV, int NW>
+__global__ __launch_bounds__(64 * NW) void residual_ln_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ dh, const float* __restrict__ out,
+    const float* __restrict__ mean_i, const float* __restrict__ rstd_i, const float* __restrict__ gamma,
+    const float* __restrict__ ma, const float* __restrict__ r, const float* __restrict__ mr,
+    const float* __restrict__ scale, const float* __restrict__ keep, float* __restrict__ da, float* __restrict__ dr,
+    float* __restrict__ ws, float* __restrict__ dscale_at, float* __restrict__ dg_at, float* __restrict__ db_at,
+    int M, int T, int C) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][3][C]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float4 as[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { as[j] = make_float4(0.f, 0.f, 0.f, 0.f); ag[j] = as[j]; ab[j] = as[j]; }
+  for (int row = blockIdx.x * NW + wid; row < M; row += gridDim.x * NW) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    const float fa = ma ? ma[row] : 1.f;
+    float fr = keep ? keep[row / T] : 1.f;
+    if (mr) fr *= mr[row];
+    float4 xh[NV], gy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      xh[j] = make_float4(0.f, 0.f, 0.f, 0.f); gy[j] = xh[j];
+      if (c < C) {
+        const float4 ov = ld4(out + (size_t)row * C + c);
+        float4 d = ld4(dh + (size_t)row * C + c);
+        const float4 g = ld4(gamma + c);
+        float4 hh;
+        hh.x = (ov.x - mean) * rstd; hh.y = (ov.y - mean) * rstd; hh.z = (ov.z - mean) * rstd; hh.w = (ov.w - mean) * rstd;
+        ag[j].x += d.x * hh.x; ag[j].y += d.y * hh.y; ag[j].z += d.z * hh.z; ag[j].w += d.w * hh.w;
+        ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+        d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;
+        s1 += d.x + d.y + d.z + d.w;
+        s2 += d.x * hh.x + d.y * hh.y + d.z * hh.z + d.w * hh.w;
+        xh[j] = hh; gy[j] = d;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < C) {
+        float4 t;
+        t.x = rstd * (gy[j].x - m1 - xh[j].x * m2); t.y = rstd * (gy[j].y - m1 - xh[j].y * m2);
+        t.z = rstd * (gy[j].z - m1 - xh[j].z * m2); t.w = rstd * (gy[j].w - m1 - xh[j].w * m2);
+        if (dout) { const float4 e = ld4(dout + (size_t)row * C + c); t.x += e.x; t.y += e.y; t.z += e.z; t.w += e.w; }
+        const float4 rv = ld4(r + (size_t)row * C + c), sc = ld4(scale + c);
+        as[j].x += t.x * rv.x * fr; as[j].y += t.y * rv.y * fr; as[j].z += t.z * rv.z * fr; as[j].w += t.w * rv.w * fr;
+        if (da) *reinterpret_cast<float4*>(da + (size_t)row * C + c) = make_float4(t.x * fa, t.y * fa, t.z * fa, t.w * fa);
+        if (dr) *reinterpret_cast<float4*>(dr + (size_t)row * C + c) =
+            make_float4(t.x * sc.x * fr, t.y * sc.y * fr, t.z * sc.z * fr, t.w * sc.w * fr);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < C) {
+      *reinterpret_cast<float4*>(red + (size_t)(wid * 3 + 0) * C + c) = as[j];
+      *reinterpret_cast<float4*>(red + (size_t)(wid * 3 + 1) * C + c) = ag[j];
+      *reinterpret_cast<float4*>(red + (size_t)(wid * 3 + 2) * C + c) = ab[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 64 * NW) {
+    const int which = i / C, c = i % C;
+    float s = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < NW; ++w_) s += red[(size_t)(w_ * 3 + which) * C + c];
+    if (dg_at) atomicAdd((which == 0 ? dscale_at : (which == 1 ? dg_at : db_at)) + c, s);
+    else ws[(size_t)blockIdx.x * 3 * C + i] = s;
+  }
+}
+
 static int ln_bwd_waves(int C) { return C <= 256 ? 16 : (C <= 512 ? 8 : 4); }
 static int ln_bwd_blocks(int M, int C) {
   static const char* e = getenv("AVDF_LN_BWD_BLOCKS");      // tuning override for tools/pw_bench.py
@@ -321,5 +452,53 @@ extern "C" int avdf_maxavgpool_bwd(const float* dy, const float* x, float* dx, i
   AVDF_REQUIRE(dy && x && dx && B > 0 && T > 0 && C > 0, "maxavgpool_bwd: bad args");
   hipLaunchKernelGGL(maxavgpool_bwd_kernel, dim3(B * cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, T, C);
   AVDF_CHECK_LAUNCH("maxavgpool_bwd");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_residual_ln_fwd(const float* a, const float* ma, const float* r, const float* mr, const float* scale,
+                                    const float* keep, const float* gamma, const float* beta, float* out, float* h,
+                                    float* mean, float* rstd, int B, int T, int C, float eps, void* stream) {
+  AVDF_REQUIRE(a && r && scale && gamma && beta && out && h && mean && rstd && B > 0 && T > 0 && C > 0, "residual_ln_fwd: bad args");
+  AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "residual_ln_fwd: C must be a multiple of 4 and <= %d", 256 * kLnMaxV);
+  AVDF_REQUIRE(aligned16(a) && aligned16(r) && aligned16(scale) && aligned16(gamma) && aligned16(beta) && aligned16(out) && aligned16(h),
+               "residual_ln_fwd: 16-byte alignment");
+  const int M = B * T;
+#define RLN_FWD(NV_) hipLaunchKernelGGL(residual_ln_fwd_kernel<NV_>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, \
+                                       a, ma, r, mr, scale, keep, gamma, beta, out, h, mean, rstd, M, T, C, eps)
+  if (C <= 256) RLN_FWD(1); else if (C <= 512) RLN_FWD(2); else if (C <= 1024) RLN_FWD(4); else RLN_FWD(8);
+#undef RLN_FWD
+  AVDF_CHECK_LAUNCH("residual_ln_fwd");
+  return AVDF_OK;
+}
+
+extern "C" int64_t avdf_residual_ln_bwd_ws(int B, int T, int C) { return (int64_t)3 * ln_bwd_blocks(B * T, C) * C; }
+
+extern "C" int avdf_residual_ln_bwd(const float* dout, const float* dh, const float* out, const float* mean,
+                                    const float* rstd, const float* gamma, const float* ma, const float* r,
+                                    const float* mr, const float* scale, const float* keep, float* da, float* dr,
+                                    float* dscale, float* dgamma, float* dbeta, float* ws, int B, int T, int C,
+                                    int accumulate, void* stream) {
+  AVDF_REQUIRE(dh && out && mean && rstd && gamma && r && scale && dscale && dgamma && dbeta && ws && B > 0 && T > 0 && C > 0,
+               "residual_ln_bwd: bad args");
+  AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "residual_ln_bwd: C must be a multiple of 4 and <= %d", 256 * kLnMaxV);
+  AVDF_REQUIRE(aligned16(dh) && aligned16(out) && aligned16(gamma) && aligned16(r) && aligned16(scale) && aligned16(dout) &&
+                   aligned16(da) && aligned16(dr), "residual_ln_bwd: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = B * T, G = ln_bwd_blocks(M, C);
+  float* sa = accumulate ? dscale : nullptr;
+  float* ga = accumulate ? dgamma : nullptr;
+  float* ba = accumulate ? dbeta : nullptr;
+#define RLN_BWD(NV_, NW_) hipLaunchKernelGGL((residual_ln_bwd_kernel<NV_, NW_>), dim3(G), dim3(64 * NW_),              \
+                                            (size_t)3 * NW_ * C * sizeof(float), st, dout, dh, out, mean, rstd, gamma,  \
+                                            ma, r, mr, scale, keep, da, dr, ws, sa, ga, ba, M, T, C)
+  if (C <= 256) RLN_BWD(1, 16); else if (C <= 512) RLN_BWD(2, 8); else if (C <= 1024) RLN_BWD(4, 4); else RLN_BWD(8, 4);
+#undef RLN_BWD
+  AVDF_CHECK_LAUNCH("residual_ln_bwd");
+  if (!accumulate) {                                                      // ws rows: [dscale | dgamma | dbeta]
+    float* dst[3] = {dscale, dgamma, dbeta};
+    const int len[3] = {C, C, C}, nsrc[3] = {1, 1, 1};
+    const int off[9] = {0, 0, 0, C, 0, 0, 2 * C, 0, 0};
+    return avdf_reduce_segments(ws, G, 3 * C, 3, dst, len, nsrc, off, 0, stream);
+  }
   return AVDF_OK;
 }

@@ -297,8 +297,11 @@ class _BlockBase(nn.Module):
         else:
             sa = sm = self._ones
             ka = km = None
-        out = ops.affine_residual(skip, out_mask, out, None, sa, ka)
-        h = self.ln2(out)
+        if self.ln2.affine:
+            out, h = ops.residual_ln(skip, out_mask, out, None, sa, ka, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+        else:
+            out = ops.affine_residual(skip, out_mask, out, None, sa, ka)
+            h = self.ln2(out)
         h = ops.conv1d(h, self.mlp[0].weight, self.mlp[0].bias, None, 1, ops.ACT_GELU)
         h = ops.conv1d(h, self.mlp[3].weight, self.mlp[3].bias, out_mask)
         return ops.affine_residual(out, None, h, None, sm, km)

@@ -656,6 +656,53 @@ def affine_residual(a, ma, r, mr, scale, keep=None):
     return AffineResidualFn.apply(a, ma, r, mr, scale, keep)
 
 
+class ResidualLnFn(torch.autograd.Function):
+    """(out, h) = (a*ma + scale*keep*(r*mr), LN(out)); `out` keeps flowing to the second residual of the block, so
+    its incoming gradient and LN's are combined in ONE backward kernel (no aten add, no separate LN backward)."""
+
+    @staticmethod
+    def forward(ctx, a, ma, r, mr, scale, keep, gamma, beta, eps):
+        ctx.main = (_main_grad(scale), _main_grad(gamma), _main_grad(beta))
+        ctx.shapes = (scale.shape, gamma.shape, beta.shape)
+        a, ma, r, mr, keep = _c(a), _c(ma), _c(r), _c(mr), _c(keep)
+        B, T, C = a.shape
+        sc, g, b = scale.contiguous().view(-1), gamma.contiguous().view(-1), beta.contiguous().view(-1)
+        out, h = torch.empty_like(a), torch.empty_like(a)
+        stats = torch.empty((2, B * T), dtype=torch.float32, device=a.device)
+        check(lib.avdf_residual_ln_fwd(_p(a), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(g), _p(b), _p(out), _p(h),
+                                       _p(stats[0]), _p(stats[1]), B, T, C, eps, _stream()), "residual_ln_fwd")
+        ctx.save_for_backward(out, stats, g, ma, r, mr, sc, keep)
+        return out, h
+
+    @staticmethod
+    def backward(ctx, dout, dh):
+        out, stats, g, ma, r, mr, sc, keep = ctx.saved_tensors
+        B, T, C = out.shape
+        dev = out.device
+        dout = None if dout is None else dout.contiguous()
+        dh = torch.zeros_like(out) if dh is None else dh.contiguous()
+        da = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        dr = torch.empty_like(out) if ctx.needs_input_grad[2] else None
+        ms, mg, mb = ctx.main
+        acc = 1 if (ms is not None and mg is not None and mb is not None) else 0
+        if acc:
+            ds, dg, db = ms.view(-1), mg.view(-1), mb.view(-1)
+        else:
+            ds, dg, db = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
+        ws = _ws(lib.avdf_residual_ln_bwd_ws(B, T, C), out)
+        check(lib.avdf_residual_ln_bwd(_p(dout), _p(dh), _p(out), _p(stats[0]), _p(stats[1]), _p(g), _p(ma), _p(r), _p(mr),
+                                       _p(sc), _p(keep), _p(da), _p(dr), _p(ds), _p(dg), _p(db), _p(ws), B, T, C, acc,
+                                       _stream()), "residual_ln_bwd")
+        if acc:
+            return da, None, dr, None, None, None, None, None, None
+        s0, s1, s2 = ctx.shapes
+        return da, None, dr, None, ds.view(s0), None, dg.view(s1), db.view(s2), None
+
+
+def residual_ln(a, ma, r, mr, scale, keep, gamma, beta, eps=1e-5):
+    return ResidualLnFn.apply(a, ma, r, mr, scale, keep, gamma, beta, eps)
+
+
 class ResampleFn(torch.autograd.Function):
     """mode 'up': y[b,t]=x[b,t//r]; mode 'down': y[b,t]=x[b,t*r] (F.interpolate nearest)."""
 

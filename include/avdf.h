@@ -259,6 +259,19 @@ int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, flo
                           int groups, int K, void* stream);
 int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream);
 
+/* ---- fused AffineDropPath residual + LayerNorm (TransformerBlock: blocks.py:1311-1313, 870-872) ------------
+ *   out = a*ma[b,t] + scale[c]*keep[b]*(r*mr[b,t]);  h = LN(out)*gamma + beta  (ma / mr / keep may be NULL)
+ * backward: dout = gradient reaching `out` from its other consumer (NULL = none), dh = gradient of h.        */
+int avdf_residual_ln_fwd(const float* a, const float* ma, const float* r, const float* mr, const float* scale,
+                         const float* keep, const float* gamma, const float* beta, float* out, float* h,
+                         float* mean, float* rstd, int B, int T, int C, float eps, void* stream);
+int64_t avdf_residual_ln_bwd_ws(int B, int T, int C);
+int avdf_residual_ln_bwd(const float* dout, const float* dh, const float* out, const float* mean,
+                         const float* rstd, const float* gamma, const float* ma, const float* r,
+                         const float* mr, const float* scale, const float* keep, float* da, float* dr,
+                         float* dscale, float* dgamma, float* dbeta, float* ws, int B, int T, int C,
+                         int accumulate, void* stream);
+
 /* ---- fused q/k/v input chains of the conv-attention blocks ---------------------------------------------
  * y_i = LN_b,i( dwconv_k3,stride s( LN_a,i(x_i) ) * mask ), i = 0..2 (query / key / value), one launch:
  * ln1 | lnq,lnk,lnv -> query_conv/key_conv/value_conv -> query_norm/key_norm/value_norm

@@ -435,3 +435,31 @@ def test_conv1d_group3_matches_three_convs(ops, B, T, C, bias, main):
         close(wd[i].main_grad if main else wd[i].grad, w64[i].grad, f"group3 dw[{i}]", rtol=5e-5)
         if bias:
             close(bd[i].main_grad if main else bd[i].grad, b64[i].grad, f"group3 db[{i}]", rtol=5e-5)
+
+
+@pytest.mark.parametrize("B,T,C,masks,main", [(2, 96, 256, True, False), (8, 768, 256, True, True), (3, 50, 64, False, False),
+                                             (2, 40, 512, True, False)])
+def test_residual_ln_matches_torch(ops, B, T, C, masks, main):
+    a, r = rnd(B, T, C, seed=1), rnd(B, T, C, seed=2)
+    scale, keep = rnd(1, C, 1, seed=3, scale=0.3), torch.tensor([1.0 / 0.9 if b % 3 else 0.0 for b in range(B)]).double()
+    gamma, beta = 1 + 0.2 * rnd(1, C, 1, seed=4), 0.2 * rnd(1, C, 1, seed=5)
+    ma = mk_mask(B, T, [T - 2 * b for b in range(B)]) if masks else None
+    mr = mk_mask(B, T, [T - 3 * b for b in range(B)]) if masks else None
+    dout, dh = rnd(B, T, C, seed=6), rnd(B, T, C, seed=7)
+    leaves = [t.clone().requires_grad_(True) for t in (a, r, scale, gamma, beta)]
+    a6, r6, s6, g6, b6 = leaves
+    o6 = a6 * (ma[..., None] if masks else 1.0) + s6.view(1, 1, C) * keep.view(B, 1, 1) * (r6 * (mr[..., None] if masks else 1.0))
+    h6 = F.layer_norm(o6, (C,), g6.view(-1), b6.view(-1), 1e-5)
+    ((o6 * dout).sum() + (h6 * dh).sum()).backward()
+    dl = [g32(t, True) for t in (a, r, scale, gamma, beta)]
+    if main:
+        for t in dl[2:]:
+            t.main_grad = torch.zeros_like(t)
+    out, h = ops.residual_ln(dl[0], None if ma is None else g32(ma), dl[1], None if mr is None else g32(mr), dl[2],
+                             g32(keep), dl[3], dl[4], 1e-5)
+    close(out, o6, "residual_ln out")
+    close(h, h6, "residual_ln h")
+    ((out * g32(dout)).sum() + (h * g32(dh)).sum()).backward()
+    for i, name in enumerate(("da", "dr", "dscale", "dgamma", "dbeta")):
+        got = dl[i].main_grad if (main and i >= 2) else dl[i].grad
+        close(got, leaves[i].grad, f"residual_ln {name}", rtol=5e-5)
