@@ -60,6 +60,7 @@ SIGNATURES = {
     "avdf_smallconv_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "avdf_smallconv_bwd_ws": (L, [I, I, I, I, I]),
     "avdf_smallconv_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "avdf_interp_linear_batched": (I, [P, P, I, L, L, I, I, I, I, I, P]),
     "avdf_interp_linear": (I, [P, P, I, I, I, I, I, P]),
     "avdf_loc_losses_ws": (L, [I, I]),
     "avdf_loc_assign": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),

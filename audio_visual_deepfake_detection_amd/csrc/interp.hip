@@ -17,7 +17,10 @@
 namespace {
 
 __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                            int Tsrc, int Csrc, int Tout, int Ctot, int coff) {
+                                                            int Tsrc, int Csrc, int Tout, int Ctot, int coff,
+                                                            long src_bstride, long dst_bstride) {
+  src += (size_t)blockIdx.y * src_bstride;        // blockIdx.y = clip of a batched call
+  dst += (size_t)blockIdx.y * dst_bstride;
   const int C4 = Csrc >> 2;
   const long total = (long)Tout * C4;
   const float scale = (float)Tsrc / (float)Tout;
@@ -56,7 +59,24 @@ extern "C" int avdf_interp_linear(const float* src, float* dst, int Tsrc, int Cs
   AVDF_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "interp_linear: 16-byte alignment");
   long g = ((long)Tout * Csrc / 4 + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, dst, Tsrc, Csrc, Tout, Ctot, coff);
+  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, dst, Tsrc, Csrc, Tout,
+                     Ctot, coff, 0L, 0L);
   AVDF_CHECK_LAUNCH("interp_linear");
+  return AVDF_OK;
+}
+
+// nb clips in one launch: clip b reads src + b*src_bstride ([Tsrc, Csrc]) and writes dst + b*dst_bstride ([Tout, Ctot])
+extern "C" int avdf_interp_linear_batched(const float* src, float* dst, int nb, int64_t src_bstride, int64_t dst_bstride,
+                                          int Tsrc, int Csrc, int Tout, int Ctot, int coff, void* stream) {
+  AVDF_REQUIRE(src && dst && nb > 0 && Tsrc > 0 && Csrc > 0 && Tout > 0 && Ctot >= coff + Csrc && coff >= 0, "interp_linear_batched: bad args");
+  AVDF_REQUIRE(Csrc % 4 == 0 && coff % 4 == 0 && Ctot % 4 == 0 && src_bstride % 4 == 0 && dst_bstride % 4 == 0,
+               "interp_linear_batched: channel counts / offsets / strides must be multiples of 4");
+  AVDF_REQUIRE(src_bstride >= (int64_t)Tsrc * Csrc && dst_bstride >= (int64_t)Tout * Ctot, "interp_linear_batched: strides too small");
+  AVDF_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "interp_linear_batched: 16-byte alignment");
+  long g = ((long)Tout * Csrc / 4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)g, nb), dim3(256), 0, (hipStream_t)stream, src, dst, Tsrc, Csrc, Tout,
+                     Ctot, coff, (long)src_bstride, (long)dst_bstride);
+  AVDF_CHECK_LAUNCH("interp_linear_batched");
   return AVDF_OK;
 }

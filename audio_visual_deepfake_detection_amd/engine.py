@@ -62,8 +62,9 @@ class TrainStep:
         dev = self.dev
 
         # ---- static inputs (raw per-clip feature streams live in HBM, time-major [T_s, C_s]) ----------
-        self.streams = [[torch.zeros(shp, dtype=torch.float32, device=dev) for shp in streams_shapes]
-                        for _ in range(batch)]
+        # one [B, T_s, C_s] buffer per stream kind (K1 runs as one launch per kind); streams[b][s] are views
+        self.stream_bufs = [torch.zeros((batch,) + tuple(shp), dtype=torch.float32, device=dev) for shp in streams_shapes]
+        self.streams = [[buf[b] for buf in self.stream_bufs] for b in range(batch)]
         assert sum(s[1] for s in streams_shapes) == self.C
         self.x = torch.zeros((batch, self.T, self.C), dtype=torch.float32, device=dev)
         self.mask = torch.ones((batch, self.T), dtype=torch.float32, device=dev)
@@ -138,8 +139,7 @@ class TrainStep:
     # --------------------------------------------------------------------------------------------
     def _stage_a(self):
         m = self.model
-        for b in range(self.B):
-            ops.interp_concat(self.streams[b], self.T, out=self.x[b])
+        ops.interp_concat_batched(self.stream_bufs, self.x)
         logits, offsets, pmask, cls_scores, _ = m.forward_features(self.x, self.mask)
         st = torch.cuda.current_stream().cuda_stream
         radius, center, ls, lw, vw, mom = self.loss_cfg
@@ -257,8 +257,9 @@ class InferStep:
         self.dev = next(model.parameters()).device
         self.B, self.T, self.C = batch, model.max_seq_len, model.input_dim
         dev = self.dev
-        self.streams = [[torch.zeros(shp, dtype=torch.float32, device=dev) for shp in streams_shapes]
-                        for _ in range(batch)]
+        # one [B, T_s, C_s] buffer per stream kind (K1 runs as one launch per kind); streams[b][s] are views
+        self.stream_bufs = [torch.zeros((batch,) + tuple(shp), dtype=torch.float32, device=dev) for shp in streams_shapes]
+        self.streams = [[buf[b] for buf in self.stream_bufs] for b in range(batch)]
         self.x = torch.zeros((batch, self.T, self.C), dtype=torch.float32, device=dev)
         self.mask = torch.ones((batch, self.T), dtype=torch.float32, device=dev)
         lens = [self.T // s for s in model.fpn_strides]
@@ -270,8 +271,7 @@ class InferStep:
     @torch.no_grad()
     def _run(self):
         m = self.model
-        for b in range(self.B):
-            ops.interp_concat(self.streams[b], self.T, out=self.x[b])
+        ops.interp_concat_batched(self.stream_bufs, self.x)
         logits, offsets, pmask, cls_scores, _ = m.forward_features(self.x, self.mask)
         segs, scores, pidx, count = ops.decode_nms(
             self.points, logits, offsets, pmask, float(m.test_pre_nms_thresh), float(m.test_duration_thresh),

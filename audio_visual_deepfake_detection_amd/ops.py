@@ -912,6 +912,20 @@ def interp_concat(streams, out_len, out=None):
     return out
 
 
+def interp_concat_batched(stream_bufs, out):
+    """stream_bufs: list of [B, T_s, C_s] tensors (one per stream kind); out [B, T, sum C_s]: one launch per stream."""
+    B, T, ctot = out.shape
+    assert out.is_contiguous()
+    off = 0
+    for s in stream_bufs:
+        assert s.is_contiguous() and s.shape[0] == B
+        Ts, Cs = int(s.shape[1]), int(s.shape[2])
+        check(lib.avdf_interp_linear_batched(_p(s), _p(out), B, Ts * Cs, T * ctot, Ts, Cs, T, ctot, off, _stream()),
+              "interp_linear_batched")
+        off += Cs
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------------

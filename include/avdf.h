@@ -182,6 +182,9 @@ int avdf_smallconv_bwd(const float* dy, const float* x, const float* w, const fl
  * the video stream when it already has max_seq_len rows, :1725).                            */
 int avdf_interp_linear(const float* src, float* dst, int Tsrc, int Csrc, int Tout, int Ctot,
                        int coff, void* stream);
+/* nb clips per launch: clip b reads src + b*src_bstride and writes dst + b*dst_bstride (strides in floats) */
+int avdf_interp_linear_batched(const float* src, float* dst, int nb, int64_t src_bstride, int64_t dst_bstride,
+                               int Tsrc, int Csrc, int Tout, int Ctot, int coff, void* stream);
 
 /* ---- training targets + losses (fused forward+gradient) ---------------------------------
  * avdf_loc_assign: label_points_single_video (av_fd_no_recon.py:502-600) for every clip.

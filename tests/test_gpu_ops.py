@@ -463,3 +463,12 @@ def test_residual_ln_matches_torch(ops, B, T, C, masks, main):
     for i, name in enumerate(("da", "dr", "dscale", "dgamma", "dbeta")):
         got = dl[i].main_grad if (main and i >= 2) else dl[i].grad
         close(got, leaves[i].grad, f"residual_ln {name}", rtol=5e-5)
+
+
+def test_interp_batched_equals_per_clip(ops):
+    g = torch.Generator().manual_seed(4)
+    bufs = [torch.randn(3, 50, 8, generator=g).cuda(), torch.randn(3, 23, 16, generator=g).cuda(), torch.randn(3, 96, 4, generator=g).cuda()]
+    out = torch.empty(3, 96, 28, device="cuda")
+    ops.interp_concat_batched(bufs, out)
+    for b in range(3):
+        assert torch.equal(out[b], ops.interp_concat([s[b] for s in bufs], 96))
