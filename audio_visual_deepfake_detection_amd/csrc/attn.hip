@@ -131,6 +131,184 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(
   dv[bs * C + h * hs + lane] = av;
 }
 
+// ---- row-vectorised variants: one wave per NTOK consecutive tokens, ALL heads at once --------------------------
+// lane = one float4 of the C = H*hs channels of a token row (C <= 256), a head = hs/4 adjacent lanes (power of two):
+// every q/k/v/out access is a coalesced 16-byte row load, per-head dot products reduce inside the lane group, and
+// the 2w+NTOK key/value rows a run of tokens needs are loaded once (the one-wave-per-(token,head) kernels above
+// re-read every row 7x through 4-byte loads: 3x HBM-side over-fetch in the PMC pass).
+constexpr int kAttnTok = 2;
+
+__device__ __forceinline__ float4 ld4a(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = L >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);     // constant offsets -> DPP / swizzle
+  return v;
+}
+
+template <int W, int L>
+__global__ __launch_bounds__(256) void local_attn_fwd_rows_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kvmask, float* __restrict__ out, float* __restrict__ probs,
+    int B, int T, int H, int hs, float scale, int runs) {
+  constexpr int w = W / 2, NR = kAttnTok + 2 * w;
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * runs) return;
+  const long b = g / runs;
+  const int t0 = (int)(g % runs) * kAttnTok;
+  const int C = H * hs, c = lane * 4;
+  const bool on = c < C;
+  const int h = on ? c / hs : 0;
+  float4 kr[NR], vr[NR];
+  float pen[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int tk = t0 - w + r;
+    kr[r] = make_float4(0.f, 0.f, 0.f, 0.f); vr[r] = kr[r]; pen[r] = -INFINITY;
+    if (tk >= 0 && tk < T) {
+      if (on) { kr[r] = ld4a(k + (b * T + tk) * C + c); vr[r] = ld4a(v + (b * T + tk) * C + c); }
+      pen[r] = (kvmask[b * T + tk] == 0.f) ? -1e4f : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kAttnTok; ++i) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    const long bt = b * T + t;
+    float4 q4 = on ? ld4a(q + bt * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    q4.x *= scale; q4.y *= scale; q4.z *= scale; q4.w *= scale;
+    float s[W];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      s[j] = group_sum<L>(dot4(q4, kr[i + j])) + pen[i + j];        // -inf outside [0,T)
+      m = fmaxf(m, s[j]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) { s[j] = __expf(s[j] - m); den += s[j]; }
+    const float inv = kvmask[bt] / den;          // masked query rows are zeroed after the softmax
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const float p = s[j] * inv;
+      if (probs && on && (lane & (L - 1)) == 0) probs[(bt * H + h) * W + j] = p;
+      o.x += p * vr[i + j].x; o.y += p * vr[i + j].y; o.z += p * vr[i + j].z; o.w += p * vr[i + j].w;
+    }
+    if (on) *reinterpret_cast<float4*>(out + bt * C + c) = o;
+  }
+}
+
+// dS (to ws) and dq
+template <int W, int L>
+__global__ __launch_bounds__(256) void local_attn_bwd_q_rows_kernel(
+    const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ probs, float* __restrict__ dq, float* __restrict__ dS,
+    int B, int T, int H, int hs, float scale, int runs) {
+  constexpr int w = W / 2, NR = kAttnTok + 2 * w;
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * runs) return;
+  const long b = g / runs;
+  const int t0 = (int)(g % runs) * kAttnTok;
+  const int C = H * hs, c = lane * 4;
+  const bool on = c < C;
+  const int h = on ? c / hs : 0;
+  float4 kr[NR], vr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int tk = t0 - w + r;
+    kr[r] = make_float4(0.f, 0.f, 0.f, 0.f); vr[r] = kr[r];
+    if (tk >= 0 && tk < T && on) { kr[r] = ld4a(k + (b * T + tk) * C + c); vr[r] = ld4a(v + (b * T + tk) * C + c); }
+  }
+#pragma unroll
+  for (int i = 0; i < kAttnTok; ++i) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    const long bt = b * T + t;
+    const float4 go = on ? ld4a(dout + bt * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float dp[W], p[W];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      p[j] = on ? probs[(bt * H + h) * W + j] : 0.f;
+      dp[j] = group_sum<L>(dot4(go, vr[i + j]));      // rows outside [0,T) are zero -> dp = 0, and p = 0 there
+      dot += p[j] * dp[j];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const float ds = p[j] * (dp[j] - dot);
+      if (on && (lane & (L - 1)) == 0) dS[(bt * H + h) * W + j] = ds;
+      acc.x += ds * kr[i + j].x; acc.y += ds * kr[i + j].y; acc.z += ds * kr[i + j].z; acc.w += ds * kr[i + j].w;
+    }
+    if (on) *reinterpret_cast<float4*>(dq + bt * C + c) = make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
+  }
+}
+
+// dk, dv gathered per key position
+template <int W>
+__global__ __launch_bounds__(256) void local_attn_bwd_kv_rows_kernel(
+    const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ probs,
+    const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv,
+    int B, int T, int H, int hs, float scale, int runs) {
+  constexpr int w = W / 2, NR = kAttnTok + 2 * w;
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * runs) return;
+  const long b = g / runs;
+  const int s0 = (int)(g % runs) * kAttnTok;
+  const int C = H * hs, c = lane * 4;
+  if (c >= C) return;
+  const int h = c / hs;
+  float4 qr[NR], gr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int t = s0 - w + r;
+    qr[r] = make_float4(0.f, 0.f, 0.f, 0.f); gr[r] = qr[r];
+    if (t >= 0 && t < T) { qr[r] = ld4a(q + (b * T + t) * C + c); gr[r] = ld4a(dout + (b * T + t) * C + c); }
+  }
+#pragma unroll
+  for (int i = 0; i < kAttnTok; ++i) {
+    const int s = s0 + i;
+    if (s >= T) break;
+    float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int t = s - (j - w);            // query t sees key s in its band slot j; its row sits at r = t - (s0 - w)
+      if (t >= 0 && t < T) {
+        const int r = i + 2 * w - j;
+        const long bt = b * T + t;
+        const float ds = dS[(bt * H + h) * W + j];
+        const float p = probs[(bt * H + h) * W + j];
+        ak.x += ds * qr[r].x; ak.y += ds * qr[r].y; ak.z += ds * qr[r].z; ak.w += ds * qr[r].w;
+        av.x += p * gr[r].x; av.y += p * gr[r].y; av.z += p * gr[r].z; av.w += p * gr[r].w;
+      }
+    }
+    const long bs = b * T + s;
+    *reinterpret_cast<float4*>(dk + bs * C + c) = make_float4(ak.x * scale, ak.y * scale, ak.z * scale, ak.w * scale);
+    *reinterpret_cast<float4*>(dv + bs * C + c) = av;
+  }
+}
+
+#define DISPATCH_L(L_, WW, CALL_L)                    \
+  switch (L_) {                                       \
+    case 1: CALL_L(WW, 1); break;                     \
+    case 2: CALL_L(WW, 2); break;                     \
+    case 4: CALL_L(WW, 4); break;                     \
+    case 8: CALL_L(WW, 8); break;                     \
+    case 16: CALL_L(WW, 16); break;                   \
+    case 32: CALL_L(WW, 32); break;                   \
+    default: CALL_L(WW, 64); break;                   \
+  }
+
+inline bool rows_path_ok(int H, int hs) {
+  const int L = hs / 4;
+  return hs % 4 == 0 && L >= 1 && (L & (L - 1)) == 0 && H * hs <= 256;
+}
+
 constexpr int kGMaxSlots = 4;   // Tk <= 256
 
 // one wave per (b, h, tq); probs [B,H,Tq,Tk]
@@ -279,6 +457,17 @@ extern "C" int avdf_local_attn_fwd(const float* q, const float* k, const float* 
   AVDF_REQUIRE(q && k && v && kvmask && out, "local_attn_fwd: null pointer");
   AVDF_REQUIRE(B > 0 && T > 0 && H > 0 && hs > 0 && hs <= 64, "local_attn_fwd: bad dims (hs=%d must be <= 64)", hs);
   hipStream_t st = (hipStream_t)stream;
+  if (rows_path_ok(H, hs) && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0)) {
+    const int runs = cdiv(T, kAttnTok);
+    const dim3 grid((unsigned)(((long)B * runs + 3) / 4));
+#define CALL_L(WW, LL) hipLaunchKernelGGL((local_attn_fwd_rows_kernel<WW, LL>), grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale, runs)
+#define CALL(WW) DISPATCH_L(hs / 4, WW, CALL_L)
+    DISPATCH_W(window, CALL)
+#undef CALL
+#undef CALL_L
+    AVDF_CHECK_LAUNCH("local_attn_fwd");
+    return AVDF_OK;
+  }
   const long waves = (long)B * T * H;
   const dim3 grid((unsigned)((waves + 3) / 4));
 #define CALL(WW) hipLaunchKernelGGL(local_attn_fwd_kernel<WW>, grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale)
@@ -296,6 +485,20 @@ extern "C" int avdf_local_attn_bwd(const float* dout, const float* q, const floa
   AVDF_REQUIRE(dout && q && k && v && probs && dq && dk && dv && ws, "local_attn_bwd: null pointer");
   AVDF_REQUIRE(B > 0 && T > 0 && H > 0 && hs > 0 && hs <= 64, "local_attn_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
+  if (rows_path_ok(H, hs) &&
+      ((((uintptr_t)dout | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0)) {
+    const int runs = cdiv(T, kAttnTok);
+    const dim3 grid((unsigned)(((long)B * runs + 3) / 4));
+#define CALL_L(WW, LL) hipLaunchKernelGGL((local_attn_bwd_q_rows_kernel<WW, LL>), grid, dim3(256), 0, st, dout, k, v, probs, dq, ws, B, T, H, hs, scale, runs)
+#define CALL(WW)                       \
+  DISPATCH_L(hs / 4, WW, CALL_L);      \
+  hipLaunchKernelGGL(local_attn_bwd_kv_rows_kernel<WW>, grid, dim3(256), 0, st, dout, q, probs, ws, dk, dv, B, T, H, hs, scale, runs)
+    DISPATCH_W(window, CALL)
+#undef CALL
+#undef CALL_L
+    AVDF_CHECK_LAUNCH("local_attn_bwd");
+    return AVDF_OK;
+  }
   const long waves = (long)B * T * H;
   const dim3 grid((unsigned)((waves + 3) / 4));
 #define CALL(WW)                                                                                             \

@@ -32,3 +32,11 @@ us = timeit(lambda: check(lib.avdf_layernorm_fwd(P(x), P(g), P(b), P(y), P(mean)
 print(f"ln_fwd: {us:.2f} us")
 us = timeit(lambda: check(lib.avdf_scale_rows(P(x), P(mask), P(y), B * T, C, st()), "sr"))
 print(f"scale_rows (copy-like, 2x6MB): {us:.2f} us  ({4*B*T*C*2/us/1e3:.0f} GB/s)")
+H, hs, W = 4, 64, 7
+q = torch.randn(B, T, C, device=dev); k = torch.randn(B, T, C, device=dev); v = torch.randn(B, T, C, device=dev)
+out = torch.empty_like(q); probs = torch.empty(B, T, H, W, device=dev)
+dq = torch.empty_like(q); dk = torch.empty_like(q); dv = torch.empty_like(q); wsa = torch.empty(B * T * H * W, device=dev)
+us = timeit(lambda: check(lib.avdf_local_attn_fwd(P(q), P(k), P(v), P(mask), P(out), P(probs), B, T, H, hs, W, 0.125, st()), "la"))
+print(f"local_attn_fwd: {us:.2f} us")
+us = timeit(lambda: check(lib.avdf_local_attn_bwd(P(dy), P(q), P(k), P(v), P(probs), P(dq), P(dk), P(dv), P(wsa), B, T, H, hs, W, 0.125, st()), "lab"))
+print(f"local_attn_bwd (2 kernels): {us:.2f} us")
