@@ -345,6 +345,61 @@ def case_datasets():
     print("[datasets] stored", len(rels), "items x 3 dataset classes")
 
 
+def synth_detections(seed, nvid=12, nlab=2):
+    """Ground truth + predictions tables for the evaluator fixtures: a few videos without predictions / without GT,
+    duplicated scores (tie order) and near-threshold overlaps."""
+    rs = np.random.RandomState(seed)
+    gt = {"video-id": [], "t-start": [], "t-end": [], "label": []}
+    pr = {"video-id": [], "t-start": [], "t-end": [], "label": [], "score": []}
+    for v in range(nvid):
+        vid = f"v{v:03d}.mp4"
+        ng = int(rs.randint(0, 4)) if v else 2
+        segs = []
+        for _ in range(ng):
+            s = float(rs.uniform(0, 25)); e = s + float(rs.uniform(0.2, 3.0))
+            segs.append((s, e))
+            gt["video-id"].append(vid); gt["t-start"].append(s); gt["t-end"].append(e); gt["label"].append(int(rs.randint(0, nlab)) * 3 + 2)
+        if v % 5 == 4:
+            continue                                   # video without predictions
+        for (s, e) in segs:
+            for _ in range(int(rs.randint(1, 4))):
+                j = rs.uniform(-0.6, 0.6, 2)
+                pr["video-id"].append(vid); pr["t-start"].append(s + j[0]); pr["t-end"].append(max(s + j[0] + 0.05, e + j[1]))
+                pr["label"].append(int(rs.randint(0, nlab)) * 3 + 2); pr["score"].append(float(np.round(rs.uniform(0, 1), 2)))
+        for _ in range(int(rs.randint(0, 3))):
+            s = float(rs.uniform(0, 28))
+            pr["video-id"].append(vid); pr["t-start"].append(s); pr["t-end"].append(s + float(rs.uniform(0.1, 2)))
+            pr["label"].append(int(rs.randint(0, nlab)) * 3 + 2); pr["score"].append(float(np.round(rs.uniform(0, 1), 2)))
+    pr["video-id"].append("ghost.mp4"); pr["t-start"].append(1.0); pr["t-end"].append(2.0); pr["label"].append(2); pr["score"].append(0.5)
+    return gt, pr
+
+
+def case_metrics():
+    """Reference evaluator (libs/utils/metrics.py:112-447) on synthetic tables.  The reference still calls `np.float`
+    (metrics.py:326-327), gone since numpy 1.24: the alias is restored HERE (generator process only)."""
+    import json
+    import tempfile
+    import pandas as pd
+    if not hasattr(np, "float"):
+        np.float = float
+    from libs.utils.metrics import ANETdetection
+    out = {}
+    for ci, seed in enumerate((11, 12, 13)):
+        gt, pr = synth_detections(seed)
+        db = {}
+        for v, s, e, l in zip(gt["video-id"], gt["t-start"], gt["t-end"], gt["label"]):
+            db.setdefault(v, {"subset": "test", "annotations": []})["annotations"].append({"segment": [s, e], "label_id": l})
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump({"database": db}, f)
+        ev = ANETdetection(f.name, "test", tiou_thresholds=np.array([0.5, 0.75, 0.95]), top_k=(1, 5), num_workers=1)
+        mAP, avg, mRecall = ev.evaluate(pd.DataFrame(pr), verbose=False)
+        os.unlink(f.name)
+        out[f"c{ci}_seed"] = np.array(seed)
+        out[f"c{ci}_mAP"], out[f"c{ci}_avg"], out[f"c{ci}_mRecall"], out[f"c{ci}_ap"] = mAP, np.array(avg), mRecall, ev.ap
+    np.savez_compressed(os.path.join(GOLD, "metrics.npz"), **out)
+    print("[metrics] stored 3 evaluator cases; mAP of the last:", mAP)
+
+
 SMALL = dict(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, head_dim=32)
 MID = dict(input_dim=192, max_seq_len=384, embd_dim=128, n_head=4, fpn_dim=128, head_dim=128)
 
@@ -356,6 +411,7 @@ def main():
     case_interp()
     case_nms()
     case_datasets()
+    case_metrics()
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
     case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
     case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)
@@ -370,4 +426,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":         # regenerate one fixture without the model cases
+        os.makedirs(GOLD, exist_ok=True)
+        import_reference()
+        case_metrics()
+    else:
+        main()
