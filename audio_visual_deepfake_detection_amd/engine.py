@@ -205,8 +205,16 @@ class TrainStep:
     def set_lr(self, lr):
         self.lr = lr
 
+    def set_lr_schedule(self, schedule):
+        """`schedule(it)` -> lr of 0-based iteration `it` (libs.utils.lr_schedulers.make_scheduler); evaluated on the
+        host before every step and written to the device scalar the captured optimiser kernel reads."""
+        self.lr_schedule = schedule
+
     def step(self):
         """One optimisation step on the data currently in the static input buffers."""
+        sched = getattr(self, "lr_schedule", None)
+        if sched is not None:
+            self.lr = float(sched(self.step_count))
         self.step_count += 1
         t = self.step_count
         self._hp_host[0] = self.lr

@@ -400,6 +400,32 @@ def case_metrics():
     print("[metrics] stored 3 evaluator cases; mAP of the last:", mAP)
 
 
+def case_lr_schedules():
+    """lr held by the reference's optimiser at every iteration: make_scheduler (train_utils.py:147-215) stepped per
+    iteration like train_one_epoch does (train_utils.py:316)."""
+    from libs.utils.train_utils import make_scheduler
+    out = {}
+    cases = [dict(learning_rate=1e-3, epochs=15, warmup=True, warmup_epochs=5, schedule_type="cosine", schedule_steps=[], schedule_gamma=0.1),
+             dict(learning_rate=2e-4, epochs=6, warmup=True, warmup_epochs=2, schedule_type="multistep", schedule_steps=[2, 4], schedule_gamma=0.1),
+             dict(learning_rate=5e-4, epochs=4, warmup=False, warmup_epochs=0, schedule_type="cosine", schedule_steps=[], schedule_gamma=0.1)]
+    for ci, oc in enumerate(cases):
+        nit = 7
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=oc["learning_rate"])
+        sch = make_scheduler(opt, oc, nit)
+        total = (oc["epochs"] + (oc["warmup_epochs"] if oc["warmup"] else 0)) * nit
+        lrs = []
+        for _ in range(total):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[f"c{ci}_lr"] = np.asarray(lrs, dtype=np.float64)
+        out[f"c{ci}_cfg"] = np.array([oc["learning_rate"], oc["epochs"], float(oc["warmup"]), oc["warmup_epochs"],
+                                      0.0 if oc["schedule_type"] == "cosine" else 1.0, nit] + list(oc["schedule_steps"]), dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "lr_schedules.npz"), **out)
+    print("[lr] stored", len(cases), "schedules")
+
+
 SMALL = dict(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, head_dim=32)
 MID = dict(input_dim=192, max_seq_len=384, embd_dim=128, n_head=4, fpn_dim=128, head_dim=128)
 
@@ -412,6 +438,7 @@ def main():
     case_nms()
     case_datasets()
     case_metrics()
+    case_lr_schedules()
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
     case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
     case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)
@@ -430,5 +457,9 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()
         case_metrics()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lr":
+        os.makedirs(GOLD, exist_ok=True)
+        import_reference()
+        case_lr_schedules()
     else:
         main()
