@@ -48,7 +48,7 @@ class TrainStep:
     """Owns the flat parameter / gradient / optimiser-state buffers and the captured step."""
 
     def __init__(self, model, batch, streams_shapes, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8,
-                 clip_grad_l2norm=1.0, ema_decay=0.999, use_graph=True, process_group=None, max_gt=8):
+                 clip_grad_l2norm=1.0, ema_decay=0.999, use_graph=True, process_group=None, max_gt=8, wgrad_side=False):
         assert next(model.parameters()).is_cuda
         self.model = model.train()
         self.dev = next(model.parameters()).device
@@ -58,6 +58,7 @@ class TrainStep:
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.use_graph = use_graph
+        self.wgrad_side = wgrad_side        # weight-gradient GEMMs on a second stream (joined at the end of backward)
         self.step_count = 0
         dev = self.dev
 
@@ -161,8 +162,13 @@ class TrainStep:
                                   self.ws_loss[self.B * self.P * 3:].data_ptr(), self.B, self.P, ls, lw, vw, mom, st),
               "loc_losses")
         self.flat_g.zero_()
-        torch.autograd.backward([logits, offsets, cls_scores], [self.dlog, self.doff, self.dvid.view_as(cls_scores)],
-                                retain_graph=self.use_graph)
+        ops.WGRAD_SIDE_STREAM = self.wgrad_side
+        try:
+            torch.autograd.backward([logits, offsets, cls_scores], [self.dlog, self.doff, self.dvid.view_as(cls_scores)],
+                                    retain_graph=self.use_graph)
+        finally:
+            ops.WGRAD_SIDE_STREAM = False
+            ops.wgrad_join()
 
     def _stage_c(self):
         st = torch.cuda.current_stream().cuda_stream

@@ -14,6 +14,7 @@ import torch
 from ._lib import lib, check
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_LEAKY = 0, 1, 2, 3
+WGRAD_SIDE_STREAM = False  # engine.TrainStep: weight-gradient GEMMs run on a second HIP stream, overlapping the dgrad chain
 FUSE_QKV_CHAIN = True      # LN -> depthwise conv -> LN of q, k, v as one fused launch (blocks._MHCABase.attend_prenorm)
 
 # fork/join of independent branches on side streams (blocks._MHCABase._attend); off by default
@@ -77,6 +78,52 @@ def _conv_tag(kind, K, stride, B, T, N):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+_wg_side = {}
+_wg_used = [False]
+
+
+class _WgradSide:
+    """Context for a weight-gradient launch of the accumulate path: its result (atomics into the flat gradient buffer)
+    is only read by the optimiser, so it does not have to sit on the critical dgrad chain.  The side stream waits for
+    the producer of `dy` and is joined ONCE, at the end of the backward pass (`wgrad_join`)."""
+
+    def __init__(self, tensors):
+        self.on = WGRAD_SIDE_STREAM and tensors[0].is_cuda
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        dev = self.tensors[0].device
+        key = (dev.type, dev.index)
+        if key not in _wg_side:
+            _wg_side[key] = torch.cuda.Stream(device=dev)
+        self.side = _wg_side[key]
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        _wg_used[0] = True
+        return self
+
+    def __exit__(self, *a):
+        if not self.on:
+            return False
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        self.ctx.__exit__(*a)
+        return False
+
+
+def wgrad_join():
+    """Make the current stream wait for every side-stream weight-gradient launch issued so far."""
+    if _wg_used[0]:
+        cur = torch.cuda.current_stream()
+        for st in _wg_side.values():
+            cur.wait_stream(st)
+        _wg_used[0] = False
 
 
 def _p(t):
@@ -157,12 +204,13 @@ class Conv1dFn(torch.autograd.Function):
             db = None
             if has_bias:
                 db = mb.view(Cout) if acc else torch.empty(Cout, dtype=w.dtype, device=w.device)
-            ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K), x)
             fl = 2.0 * B * Tout * Cout * Cin * K
-            _timed(f"conv_wgrad_k{K}s{stride}_{'n64' if Cout * Cin * K <= 512 * 1024 else 'n128'}+reduce", fl,
-                   lambda: check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws),
-                                                            B, Tin, Cin, Tout, Cout, K, stride, act, acc, st),
-                                 "conv1d_bwd_weight"))
+            with _WgradSide([dy, x, mask, ypre] if acc else [x[:0].cpu()]):
+                ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K), x)
+                _timed(f"conv_wgrad_k{K}s{stride}_{'n64' if Cout * Cin * K <= 512 * 1024 else 'n128'}+reduce", fl,
+                       lambda: check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws),
+                                                                B, Tin, Cin, Tout, Cout, K, stride, act, acc, _stream()),
+                                     "conv1d_bwd_weight"))
             if acc:
                 dw = db = None
         return dx, dw, db, None, None, None
@@ -220,11 +268,12 @@ class Conv1dGroup3Fn(torch.autograd.Function):
         if has_bias:
             dbs = [m.view(Cout) for m in mb] if acc else [torch.empty(Cout, dtype=torch.float32, device=dev) for _ in range(3)]
         per = (int(lib.avdf_conv1d_bwd_weight_ws(B, T, Cin, Cout, K)) + 3) // 4 * 4
-        wsb = _ws(3 * per, xs[0])
-        _timed(f"conv_wgrad3_k{K}s1+reduce", fl, lambda: check(
-            lib.avdf_conv1d_bwd_weight_grouped(3, _ptr_table(dys), _ptr_table(xs), None, None, _ptr_table(dws),
-                                               _ptr_table(dbs) if has_bias else None, _p(wsb), B, T, Cin, T, Cout, K, 1,
-                                               ACT_NONE, acc, st), "conv1d_bwd_weight_grouped"))
+        with _WgradSide(dys + xs if acc else [xs[0][:0].cpu()]):
+            wsb = _ws(3 * per, xs[0])
+            _timed(f"conv_wgrad3_k{K}s1+reduce", fl, lambda: check(
+                lib.avdf_conv1d_bwd_weight_grouped(3, _ptr_table(dys), _ptr_table(xs), None, None, _ptr_table(dws),
+                                                   _ptr_table(dbs) if has_bias else None, _p(wsb), B, T, Cin, T, Cout, K, 1,
+                                                   ACT_NONE, acc, _stream()), "conv1d_bwd_weight_grouped"))
         if acc:
             return (*dxs, None, None, None, None, None, None)
         return (*dxs, *dws, *(dbs if has_bias else [None] * 3))

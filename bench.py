@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wgrad-side", action="store_true",
+                    help="weight-gradient GEMMs on a second HIP stream (measured slower inside hipGraphs: 558 vs 611 clips/s)")
     ap.add_argument("--branch-streams", action="store_true", help="run the q/k/v chains on three HIP streams")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "e2e"],
                     help="train (headline), infer (K1 -> fwd -> decode+NMS), e2e (raw PCM + frames -> 3 encoders -> infer)")
@@ -168,7 +170,7 @@ def main():
     if args.mode == "train":
         eng = TrainStep(model, B, STREAMS, lr=cfg["opt"]["learning_rate"] * world,        # train.py:60 LR rule
                         weight_decay=cfg["opt"]["weight_decay"], clip_grad_l2norm=cfg["train_cfg"]["clip_grad_l2norm"],
-                        use_graph=not args.no_graph, process_group=pg)
+                        use_graph=not args.no_graph, process_group=pg, wgrad_side=args.wgrad_side)
     else:
         eng = InferStep(model, B, STREAMS, use_graph=not args.no_graph)
     load_batch(eng, rank * B)
