@@ -25,7 +25,8 @@ def _stale(obj, deps):
 def build(force=False, verbose=False):
     obj_dir = os.path.join(HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "avdf.h")]
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_tuned.inc"),
+            os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "avdf.h")]
     jobs = []
     for s in SOURCES:
         src = os.path.join(HERE, s)

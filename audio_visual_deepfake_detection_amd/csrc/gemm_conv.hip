@@ -668,7 +668,38 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // as needed to put ~1024+ wave-quads on the chip.
 // tile 0: 128x128  1: 64x128  2: 64x64  3: 32x128
 struct TilePlan { int tile, kg; };
-inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false) {
+
+// ---- measured plans ----------------------------------------------------------------------------------------
+// tools/autotune.py times every (tile, K-groups) / (token-splits, K-groups) choice for the GEMM shapes of a training
+// step on the GPU and writes gemm_tuned.inc; shapes not in the table use the heuristics below.
+struct TunedPlan { int kind, K, stride, M, N, Kred, a, b; };   // kind 0 fwd / 1 dgrad: (tile, kg); 2 wgrad: (splits, kg)
+static const TunedPlan kTuned[] = {
+#include "gemm_tuned.inc"
+    {-1, 0, 0, 0, 0, 0, 0, 0}};
+inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, int Kred) {
+  for (const TunedPlan* t = kTuned; t->kind >= 0; ++t)
+    if (t->kind == kind && t->K == K && t->stride == stride && t->M == M && t->N == N && t->Kred == Kred) return t;
+  return nullptr;
+}
+// process-wide override used by the tuner: g_override[kind] = {a, b}, -1 = off
+static int g_override[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+
+inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, int stride = 0, int Kred = 0) {
+  {
+    const int kind = dgrad ? 1 : 0;
+    const int mk_[4] = {1, 2, 4, 4};
+    if (g_override[kind][0] >= 0) {
+      TilePlan o{g_override[kind][0], g_override[kind][1]};
+      if (o.tile > 3) o.tile = 3;
+      if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
+      if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
+      return o;
+    }
+    if (K > 0) {
+      const TunedPlan* t = tuned_lookup(kind, K, stride, B * T, N, Kred);
+      if (t) return TilePlan{t->a, t->b};
+    }
+  }
   const int bm[4] = {128, 64, 64, 32}, bn[4] = {128, 128, 64, 128};
   TilePlan p{0, 1};
   long best_blocks = -1;
@@ -695,7 +726,7 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false) {
 }
 
 struct WgradPlan { int tilesPerClip, splits, tilesPerSplit, mtiles, ctiles, kg; bool small; };
-inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K, int nprob = 1) {
+inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K, int nprob = 1, int stride_for_table = 0) {
   WgradPlan p;
   p.small = ((int64_t)Cout * Cin * K <= 512 * 1024);
   const int KT = p.small ? 128 : 64;           // tokens per K-tile (must match the launch below)
@@ -707,7 +738,22 @@ inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K, int nprob
   const int tiles = p.mtiles * p.ctiles * nprob;
   p.kg = p.small ? (tiles >= 256 ? 1 : (tiles >= 64 ? 2 : 4)) : (tiles >= 256 ? 1 : 2);
   if (K == 3 && p.kg > 2) p.kg = 2;            // 3 accumulator sets per wave: keep the LDS reduction small
-  int want = cdiv(1024, tiles * p.kg);
+  // token splits: every split re-writes the whole weight gradient (atomics or a slab), so the k=3 / big-weight
+  // problems want few of them (autotune: 1-4 splits beat the old "1024 workgroups" rule by 1.3-2.3x there)
+  int want = cdiv(K == 3 ? 256 : 1024, tiles * p.kg);
+  {
+    int a = -1, b = -1;
+    if (g_override[2][0] >= 0) { a = g_override[2][0]; b = g_override[2][1]; }
+    else if (stride_for_table > 0) {
+      const TunedPlan* t = tuned_lookup(2, K, stride_for_table, B * Tout, Cout * nprob, Cin);
+      if (t) { a = t->a; b = t->b; }
+    }
+    if (a > 0) {
+      want = a;
+      const int maxkg = (K == 3) ? 2 : (p.small ? 4 : 2);
+      if (b == 1 || b == 2 || b == 4) p.kg = b > maxkg ? maxkg : b;
+    }
+  }
   if (want < 1) want = 1;
   if (want > total) want = total;
   p.tilesPerSplit = cdiv(total, want);
@@ -754,7 +800,7 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
 
 static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
                              int stride, int pad, int ldx, int ldw, int ldy, int act, hipStream_t st) {
-  const TilePlan plan = pick_tile(B * nprob, Tout, Cout);
+  const TilePlan plan = pick_tile(B * nprob, Tout, Cout, false, K, stride, Cin);
 #define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
   do {                                                                                                  \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
@@ -833,7 +879,7 @@ extern "C" int avdf_conv1d_fwd_ex(const float* x, const float* w, const float* b
 
 static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
                                int stride, int act, hipStream_t st) {
-  const TilePlan plan = pick_tile(B * nprob, Tin, Cin, true);
+  const TilePlan plan = pick_tile(B * nprob, Tin, Cin, true, K, stride, Cout);
 #define LAUNCH_DG(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                                  \
   do {                                                                                                    \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                             \
@@ -882,8 +928,12 @@ extern "C" int avdf_conv1d_bwd_data_grouped(int n, const float* const* dy, const
 }
 
 extern "C" int64_t avdf_conv1d_bwd_weight_ws(int B, int Tout, int Cin, int Cout, int K) {
-  const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
-  const int64_t slab = (p.splits > 1) ? (int64_t)p.splits * Cout * Cin * K : 0;
+  int splits = 1;                      // the stride is not known here: cover the plan of either stride
+  for (int s_ = 0; s_ <= 2; ++s_) {
+    const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, 1, s_);
+    if (p.splits > splits) splits = p.splits;
+  }
+  const int64_t slab = (splits > 1) ? (int64_t)splits * Cout * Cin * K : 0;
   return slab + (int64_t)kColsumBlocks * Cout;
 }
 
@@ -929,7 +979,7 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_weight: Tout inconsistent");
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws) && (!ypre || aligned16(ypre)), "conv1d_bwd_weight: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K);
+  const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, 1, stride);
   // accumulate != 0 (engine path): partial tiles and the bias column sums are added into dw / dbias with
   // float atomics -- one launch, no slabs; gradients then differ run-to-run in the last bits, like any
   // atomics-based wgrad.  accumulate == 0: deterministic slabs + reducer.
@@ -983,6 +1033,14 @@ extern "C" int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, con
     g.mask[i] = mask ? mask[j] : nullptr; g.ypre[i] = ypre ? ypre[j] : nullptr; g.dbias[i] = dbias ? dbias[j] : nullptr;
     AVDF_REQUIRE(aligned16(g.dy[i]) && aligned16(g.x[i]) && aligned16(g.ypre[i]), "conv1d_bwd_weight_grouped: 16-byte alignment");
   }
-  WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, n);
+  WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, n, stride);
   return conv1d_wgrad_launch(g, n, p, B, Tin, Cin, Tout, Cout, K, stride, act, accumulate, true, (hipStream_t)stream);
+}
+
+// tuner hook (tools/autotune.py): kind 0 fwd / 1 dgrad: (tile, K-groups); 2 wgrad: (token splits, K-groups); a < 0 = off
+extern "C" int avdf_gemm_override(int kind, int a, int b) {
+  AVDF_REQUIRE(kind >= 0 && kind < 3, "gemm_override: kind in 0..2");
+  g_override[kind][0] = a;
+  g_override[kind][1] = b;
+  return AVDF_OK;
 }

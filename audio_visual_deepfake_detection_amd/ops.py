@@ -45,7 +45,12 @@ def profile_end():
     return out
 
 
-def _timed(tag, flops, fn):
+shape_log = None     # tools/autotune.py: dict (kind, K, stride, B, Tin, Cin, Cout, nprob) -> launches per step
+
+
+def _timed(tag, flops, fn, shape=None):
+    if shape_log is not None and shape is not None:
+        shape_log[shape] = shape_log.get(shape, 0) + 1
     if _prof is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -178,7 +183,7 @@ class Conv1dFn(torch.autograd.Function):
         fl = 2.0 * B * Tout * Cout * Cin * K
         _timed(_conv_tag("fwd", K, stride, B, Tout, Cout), fl, lambda: check(
             lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
-                                K, stride, act, _stream()), "conv1d_fwd"))
+                                K, stride, act, _stream()), "conv1d_fwd"), ("fwd", K, stride, B, Tin, Cin, Cout, 1))
         ctx.save_for_backward(x, w, mask, ypre)
         ctx.cfg = (B, Tin, Cin, Tout, Cout, K, stride, act, bias is not None)
         ctx.main = (_main_grad(w0), _main_grad(b0))
@@ -196,7 +201,7 @@ class Conv1dFn(torch.autograd.Function):
             fl = 2.0 * B * Tout * Cout * Cin * K
             _timed(_conv_tag("dgrad", K, stride, B, Tin, Cin), fl, lambda: check(
                 lib.avdf_conv1d_bwd_data(_p(dy), _p(w), _p(mask), _p(ypre), _p(dx), B, Tin, Cin, Tout, Cout,
-                                         K, stride, act, st), "conv1d_bwd_data"))
+                                         K, stride, act, st), "conv1d_bwd_data"), ("dgrad", K, stride, B, Tin, Cin, Cout, 1))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             mw, mb = ctx.main
             acc = 1 if mw is not None else 0
@@ -210,7 +215,7 @@ class Conv1dFn(torch.autograd.Function):
                 _timed(f"conv_wgrad_k{K}s{stride}_{'n64' if Cout * Cin * K <= 512 * 1024 else 'n128'}+reduce", fl,
                        lambda: check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws),
                                                                 B, Tin, Cin, Tout, Cout, K, stride, act, acc, _stream()),
-                                     "conv1d_bwd_weight"))
+                                     "conv1d_bwd_weight"), ("wgrad", K, stride, B, Tin, Cin, Cout, 1))
             if acc:
                 dw = db = None
         return dx, dw, db, None, None, None
@@ -240,7 +245,7 @@ class Conv1dGroup3Fn(torch.autograd.Function):
         _timed(_conv_tag("fwd3", K, 1, 3 * B, T, Cout), fl, lambda: check(
             lib.avdf_conv1d_fwd_grouped(3, _ptr_table(xs), _ptr_table(ws_), _ptr_table(bs) if has_bias else None, None,
                                         _ptr_table(ys), None, B, T, Cin, T, Cout, K, 1, ACT_NONE, _stream()),
-            "conv1d_fwd_grouped"))
+            "conv1d_fwd_grouped"), ("fwd", K, 1, B, T, Cin, Cout, 3))
         ctx.save_for_backward(*xs, *ws_)
         ctx.cfg = (B, T, Cin, Cout, K, has_bias)
         ctx.main = ([_main_grad(t) for t in ws0], [_main_grad(t) for t in bs0])
@@ -260,7 +265,8 @@ class Conv1dGroup3Fn(torch.autograd.Function):
             dxs = [torch.empty_like(x) for x in xs]
             _timed(_conv_tag("dgrad3", K, 1, 3 * B, T, Cin), fl, lambda: check(
                 lib.avdf_conv1d_bwd_data_grouped(3, _ptr_table(dys), _ptr_table(ws_), None, None, _ptr_table(dxs), B, T, Cin,
-                                                 T, Cout, K, 1, ACT_NONE, st), "conv1d_bwd_data_grouped"))
+                                                 T, Cout, K, 1, ACT_NONE, st), "conv1d_bwd_data_grouped"),
+                   ("dgrad", K, 1, B, T, Cin, Cout, 3))
         mw, mb = ctx.main
         acc = 1 if all(m is not None for m in mw) and (not has_bias or all(m is not None for m in mb)) else 0
         dws = [m.view(ws_[0].shape) for m in mw] if acc else [torch.empty_like(w) for w in ws_]
@@ -273,7 +279,8 @@ class Conv1dGroup3Fn(torch.autograd.Function):
             _timed(f"conv_wgrad3_k{K}s1+reduce", fl, lambda: check(
                 lib.avdf_conv1d_bwd_weight_grouped(3, _ptr_table(dys), _ptr_table(xs), None, None, _ptr_table(dws),
                                                    _ptr_table(dbs) if has_bias else None, _p(wsb), B, T, Cin, T, Cout, K, 1,
-                                                   ACT_NONE, acc, _stream()), "conv1d_bwd_weight_grouped"))
+                                                   ACT_NONE, acc, _stream()), "conv1d_bwd_weight_grouped"),
+                   ("wgrad", K, 1, B, T, Cin, Cout, 3))
         if acc:
             return (*dxs, None, None, None, None, None, None)
         return (*dxs, *dws, *(dbs if has_bias else [None] * 3))

@@ -58,6 +58,10 @@ int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* c
                                    int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int act,
                                    int accumulate, void* stream);
 
+/* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..3, K-groups); 2 wgrad:
+ * (token splits, K-groups)); a < 0 restores the table / heuristic.  Used by tools/autotune.py only.            */
+int avdf_gemm_override(int kind, int a, int b);
+
 /* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the
  * wav2vec2 feature extractor, fairseq ConvFeatureExtractionModel named at audio_feature/emotion_audio/upstream/
  * models/audio.py:12-17,66-71) and explicit row strides (floats), so x / w / y may be column slices of wider
