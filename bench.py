@@ -127,12 +127,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, (world, args.gpus)
+    # AVDF_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives staged through the host); the measured configuration is always one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("AVDF_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     from audio_visual_deepfake_detection_amd import build_model

@@ -1,0 +1,30 @@
+"""List the aten ops (torch-side glue) executed by one eager training step.  python tools/aten_ops.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from audio_visual_deepfake_detection_amd import build_model
+from audio_visual_deepfake_detection_amd.engine import TrainStep
+STREAMS = [(768, 256), (383, 2048), (1535, 768)]
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model, cfg = build_model("deepfake_exp10.yaml")
+eng = TrainStep(model.to(dev), 8, STREAMS, use_graph=False)
+for b in range(8):
+    for dst in eng.streams[b]:
+        dst.normal_()
+    if b % 2 == 0:
+        eng.gt[b, 0] = torch.tensor([100.0, 130.0]); eng.ngt[b] = 1
+eng.step(); eng.step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+    eng.step()
+    torch.cuda.synchronize()
+META = {"aten::empty", "aten::view", "aten::empty_strided", "aten::empty_like", "aten::select", "aten::as_strided", "aten::narrow",
+        "aten::slice", "aten::reshape", "aten::expand", "aten::squeeze", "aten::unsqueeze", "aten::t", "aten::transpose", "aten::detach",
+        "aten::alias", "aten::_unsafe_view", "aten::contiguous", "aten::view_as", "aten::permute", "aten::result_type", "aten::to",
+        "aten::lift_fresh", "aten::resolve_conj", "aten::resolve_neg", "aten::item", "aten::_local_scalar_dense", "aten::unbind"}
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.key not in META]
+rows.sort(key=lambda e: -e.count)
+for e in rows[:60]:
+    print(f"{e.key:32s} n={e.count:4d} shapes={str(e.input_shapes)[:110]}")
