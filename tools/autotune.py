@@ -75,14 +75,18 @@ def bench_shape(shape, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, nargs="+", default=[8], help="clips per GPU per step; several values -> one merged table")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                   "audio_visual_deepfake_detection_amd", "csrc", "gemm_tuned.inc"))
     ap.add_argument("--report", default="gpurun_out/autotune.json")
     args = ap.parse_args()
-    log = collect(args.batch)
-    print(f"{len(log)} distinct GEMM shapes, {sum(log.values())} launches per step", flush=True)
+    log = {}
+    for bsz in args.batch:
+        lg = collect(bsz)
+        print(f"batch {bsz}: {len(lg)} distinct GEMM shapes, {sum(lg.values())} launches per step", flush=True)
+        for k, v in lg.items():
+            log.setdefault(k, v)
     rows, report, saved = [], [], 0.0
     for shape, cnt in sorted(log.items(), key=lambda kv: kv[0]):
         base, best, best_us, res = bench_shape(shape, args.iters)
@@ -101,7 +105,7 @@ def main():
                 key = (2, K, s, B * Tout, Cout * n, Cin)
             rows.append("    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s x%d: %.1f -> %.1f us" % (*key, best[0], best[1], kind, cnt, base, best_us))
     with open(args.out, "w") as f:
-        f.write("// generated by tools/autotune.py (B=%d clips, exp10) -- {kind, K, stride, M, N, Kred, a, b},\n" % args.batch)
+        f.write("// generated by tools/autotune.py (B=%s clips, exp10) -- {kind, K, stride, M, N, Kred, a, b},\n" % ",".join(map(str, args.batch)))
         f.write("\n".join(rows) + ("\n" if rows else ""))
     os.makedirs(os.path.dirname(args.report) or ".", exist_ok=True)
     json.dump(report, open(args.report, "w"), indent=1)
