@@ -687,15 +687,15 @@ static int g_override[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
 inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, int stride = 0, int Kred = 0) {
   {
     const int kind = dgrad ? 1 : 0;
-    const int mk_[4] = {1, 2, 4, 4};
+    const int mk_[5] = {1, 2, 4, 4, 2};
     if (g_override[kind][0] >= 0) {
       TilePlan o{g_override[kind][0], g_override[kind][1]};
-      if (o.tile > 3) o.tile = 3;
+      if (o.tile > 4) o.tile = 4;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
       return o;
     }
-    if (K > 0) {
+    if (K > 0 && g_override[kind][0] != -2) {          // -2: heuristic only (the tuner's baseline)
       const TunedPlan* t = tuned_lookup(kind, K, stride, B * T, N, Kred);
       if (t) return TilePlan{t->a, t->b};
     }
@@ -744,7 +744,7 @@ inline WgradPlan wgrad_plan(int B, int Tout, int Cin, int Cout, int K, int nprob
   {
     int a = -1, b = -1;
     if (g_override[2][0] >= 0) { a = g_override[2][0]; b = g_override[2][1]; }
-    else if (stride_for_table > 0) {
+    else if (stride_for_table > 0 && g_override[2][0] != -2) {
       const TunedPlan* t = tuned_lookup(2, K, stride_for_table, B * Tout, Cout * nprob, Cin);
       if (t) { a = t->a; b = t->b; }
     }
@@ -785,8 +785,12 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
 
 // K-tile depth per tile shape: deep enough that one tile of MFMAs (>= 2-4k cycles per group) covers
 // the global-load latency of the next one at ~1 wave per SIMD.
-#define AVDF_GEMM_DISPATCH(KS_, S_, KC0_, KC1_, KC2_, KC3_, L)                     \
+// tile 4 = 256x64 (4x1 waves of 64x64, the conv3d shape: 4 MFMAs per 4 LDS reads, long stages); only reached
+// through the tuned table / the tuner override
+#define AVDF_GEMM_DISPATCH(KS_, S_, KC0_, KC1_, KC2_, KC3_, KC4_, L)               \
   switch (plan.tile * 8 + plan.kg) {                                               \
+    case 4 * 8 + 1: L(KS_, S_, KC4_, 4, 1, 2, 2, 1); break;                        \
+    case 4 * 8 + 2: L(KS_, S_, KC4_, 4, 1, 2, 2, 2); break;                        \
     case 0 * 8 + 1: L(KS_, S_, KC0_, 2, 2, 2, 2, 1); break;                        \
     case 1 * 8 + 1: L(KS_, S_, KC1_, 2, 2, 1, 2, 1); break;                        \
     case 1 * 8 + 2: L(KS_, S_, KC1_, 2, 2, 1, 2, 2); break;                        \
@@ -809,10 +813,10 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy);          \
   } while (0)
-  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_FWD) }
-  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_FWD) }
-  else if (K == 2 && stride == 2) { AVDF_GEMM_DISPATCH(2, 2, 64, 64, 64, 64, LAUNCH_FWD) }
-  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, LAUNCH_FWD) }
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, LAUNCH_FWD) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, LAUNCH_FWD) }
+  else if (K == 2 && stride == 2) { AVDF_GEMM_DISPATCH(2, 2, 64, 64, 64, 64, 32, LAUNCH_FWD) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, LAUNCH_FWD) }
 #undef LAUNCH_FWD
   AVDF_CHECK_LAUNCH("conv1d_fwd");
   return AVDF_OK;
@@ -888,9 +892,9 @@ static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin,
     hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);                                \
   } while (0)
-  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, LAUNCH_DG) }
-  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, LAUNCH_DG) }
-  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, LAUNCH_DG) }
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, LAUNCH_DG) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, LAUNCH_DG) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, LAUNCH_DG) }
 #undef LAUNCH_DG
   AVDF_CHECK_LAUNCH("conv1d_bwd_data");
   return AVDF_OK;

@@ -59,7 +59,7 @@ int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* c
                                    int accumulate, void* stream);
 
 /* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..3, K-groups); 2 wgrad:
- * (token splits, K-groups)); a < 0 restores the table / heuristic.  Used by tools/autotune.py only.            */
+ * (token splits, K-groups)); a = -1 restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only. */
 int avdf_gemm_override(int kind, int a, int b);
 
 /* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the
