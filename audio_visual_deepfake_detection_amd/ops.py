@@ -61,24 +61,10 @@ def _timed(tag, flops, fn, shape=None):
     return r
 
 
-def _pick_tile(B, T, N):
-    """Mirror of pick_tile() in csrc/gemm_conv.hip (only used to label profile records)."""
-    bm, bn = (128, 64, 64, 32), (128, 128, 64, 128)
-    best, best_blocks = 0, -1
-    for c in range(4):
-        blocks = B * -(-T // bm[c]) * -(-N // bn[c])
-        if blocks >= 512:
-            return c
-        if blocks > best_blocks:
-            best, best_blocks = c, blocks
-    return best
-
-
 def _conv_tag(kind, K, stride, B, T, N):
-    tile = _pick_tile(B, T, N)
-    if kind.startswith("dgrad") and tile == 2:
-        tile = 3                                   # dgrad prefers 32x128 over 64x64 (pick_tile(..., dgrad=true))
-    return f"conv_{kind}_k{K}s{stride}_{('128x128', '64x128', '64x64', '32x128')[tile]}"
+    """Kernel class of a profile record: direction + kernel size + stride (the tile / K-group variant inside a class is
+    a plan choice -- table or heuristic -- and is not part of the label)."""
+    return f"conv_{kind}_k{K}s{stride}"
 
 
 def _stream():
@@ -212,7 +198,7 @@ class Conv1dFn(torch.autograd.Function):
             fl = 2.0 * B * Tout * Cout * Cin * K
             with _WgradSide([dy, x, mask, ypre] if acc else [x[:0].cpu()]):
                 ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, Tout, Cin, Cout, K), x)
-                _timed(f"conv_wgrad_k{K}s{stride}_{'n64' if Cout * Cin * K <= 512 * 1024 else 'n128'}+reduce", fl,
+                _timed(f"conv_wgrad_k{K}s{stride}", fl,
                        lambda: check(lib.avdf_conv1d_bwd_weight(_p(dy), _p(x), _p(mask), _p(ypre), _p(dw), _p(db), _p(ws),
                                                                 B, Tin, Cin, Tout, Cout, K, stride, act, acc, _stream()),
                                      "conv1d_bwd_weight"), ("wgrad", K, stride, B, Tin, Cin, Cout, 1))
@@ -276,7 +262,7 @@ class Conv1dGroup3Fn(torch.autograd.Function):
         per = (int(lib.avdf_conv1d_bwd_weight_ws(B, T, Cin, Cout, K)) + 3) // 4 * 4
         with _WgradSide(dys + xs if acc else [xs[0][:0].cpu()]):
             wsb = _ws(3 * per, xs[0])
-            _timed(f"conv_wgrad3_k{K}s1+reduce", fl, lambda: check(
+            _timed(f"conv_wgrad3_k{K}s1", fl, lambda: check(
                 lib.avdf_conv1d_bwd_weight_grouped(3, _ptr_table(dys), _ptr_table(xs), None, None, _ptr_table(dws),
                                                    _ptr_table(dbs) if has_bias else None, _p(wsb), B, T, Cin, T, Cout, K, 1,
                                                    ACT_NONE, acc, _stream()), "conv1d_bwd_weight_grouped"),

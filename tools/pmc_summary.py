@@ -7,9 +7,6 @@ on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZ
 float atomics.  Kernel classes are keyed both by the full rocprof kernel name and by the bench.py roofline tag."""
 import csv, glob, json, os, re, sys
 
-TILES = {(2, 2, 2, 2): "128x128", (2, 2, 1, 2): "64x128", (2, 2, 1, 1): "64x64", (1, 4, 1, 1): "32x128"}
-
-
 def load(d, counter):
     f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[-1]
     agg = {}
@@ -23,14 +20,10 @@ def load(d, counter):
 
 
 def tag_of(name):
-    m = re.search(r"conv_(fwd|dgrad|wgrad)_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
-    if not m:
-        return None
-    kind, ks, s, wm, wn, mi, ni = m.group(1), *[int(m.group(i)) for i in range(2, 8)]
-    if kind == "wgrad":      # bench.py tags wgrad by weight size: n64 = 64x64 output tile / 128 tokens, n128 = 128x64 / 64
-        return f"conv_wgrad_k{ks}s{s}_{'n64' if mi == 1 else 'n128'}+reduce"
-    tile = TILES.get((wm, wn, mi, ni))
-    return None if tile is None else f"conv_{kind}_k{ks}s{s}_{tile}"
+    """bench.py roofline class of a rocprof kernel name: conv_{fwd,dgrad,wgrad}_k{K}s{S} (all tile variants folded;
+    the grouped q/k/v launches run the same kernels and are folded in too)."""
+    m = re.search(r"conv_(fwd|dgrad|wgrad)_kernel<(\d+), (\d+),", name)
+    return None if not m else f"conv_{m.group(1)}_k{m.group(2)}s{m.group(3)}"
 
 
 def main():
