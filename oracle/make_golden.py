@@ -445,6 +445,7 @@ def main():
     case_train("train_small", R.make_cfg(**SMALL), [192, 150, 180, 192], 3, 9, ctx)
     case_train("train_mid", R.make_cfg(**MID), [384, 300, 350, 200], 7, 10, ctx)
     case_forward("fwd_exp10", R.make_cfg(), [768, 700], 21, 22, ctx)
+    case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, ctx)          # full-size exp10, 4 clips
     case_forward("fwd_the_small", R.make_cfg(variant="the", **SMALL), [192, 133], 31, 32, ctx)
     case_train("train_the_small", R.make_cfg(variant="the", **SMALL), [192, 150, 180, 192], 33, 34, ctx)
     case_forward("fwd_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 140], 41, 42, ctx)
@@ -457,6 +458,10 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()
         case_metrics()
+    elif len(sys.argv) > 1 and sys.argv[1] == "train_exp10":
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, import_reference())
     elif len(sys.argv) > 1 and sys.argv[1] == "lr":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()

@@ -59,6 +59,9 @@ CONV_CASES = [
     (6, 768, 256, 128, 1, 1, True, False, 2),
     (1, 24, 2048, 256, 3, 2, True, True, 0),      # deep K loop, tiny T
     (4, 1, 512, 256, 1, 1, False, False, 0),      # Linear on [B, 2H]
+    (4, 192, 512, 1024, 3, 2, True, True, 0),     # contraction down_3 at full size: big-weight wgrad, 2 token tiles per clip
+    (4, 384, 256, 512, 3, 2, True, True, 0),      # contraction down_2
+    (8, 768, 256, 1024, 1, 1, True, False, 2),    # fc1 at full size
 ]
 
 
