@@ -82,6 +82,19 @@ __device__ __forceinline__ void kgroup_reduce(floatx16 (&acc)[NACC], float* red,
   }
 }
 
+// ---- split-bf16 ("bf16x3") operands: x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a*b ~ hi*hi + hi*lo + lo*hi
+// keeps ~16 mantissa bits per operand (relative error ~2^-17 per product, fp32 accumulation) at 3 bf16 MFMAs
+// (32x32x16) per 16-deep k-step instead of 8 fp32 MFMAs (32x32x2): ~5x the matrix-core rate.  Optional GEMM mode.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo) {
+  const __bf16 h0 = (__bf16)v.x, h1 = (__bf16)v.y, h2 = (__bf16)v.z, h3 = (__bf16)v.w;
+  const __bf16 l0 = (__bf16)(v.x - (float)h0), l1 = (__bf16)(v.y - (float)h1), l2 = (__bf16)(v.z - (float)h2),
+               l3 = (__bf16)(v.w - (float)h3);
+  hi.x = bf16_bits(h0) | ((unsigned)bf16_bits(h1) << 16); hi.y = bf16_bits(h2) | ((unsigned)bf16_bits(h3) << 16);
+  lo.x = bf16_bits(l0) | ((unsigned)bf16_bits(l1) << 16); lo.y = bf16_bits(l2) | ((unsigned)bf16_bits(l3) << 16);
+}
+
 // q-th float4 of a [rows][W4 float4] tile -> (row, c4).  A half-wave covers 4 rows x 8 float4 columns, so
 // the 32 lanes that scatter the same component of their float4 into a row-major LDS tile whose row stride is
 // = 1 (mod 32) hit 32 different banks (a plain row-major walk is a 4-way conflict); a wave still reads
@@ -141,7 +154,7 @@ __device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3 = false>
 __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
     FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy) {
   const int prob = blockIdx.z;
@@ -164,11 +177,20 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   constexpr int A4 = KC / 4, B4 = KB / 4;
   constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (BN * B4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = BN * LDB;
-  constexpr int SM = cmax(AS + BSZ, KG * BM * (BN + 4));
   constexpr int KCG = KC / KG;
+  // BF3: two bf16 planes (hi, lo) per operand; rows padded by 8 elements (16 B) so the 16-byte fragment reads of the
+  // 32 row-lanes are conflict-free; the B rows are tap-major [k][c] (8 consecutive channels per fragment)
+  constexpr int LDAH = KC + 8, LDBH = KB + 8;
+  constexpr int ASH = RA * LDAH, BSH = BN * LDBH;
+  static_assert(!BF3 || KCG % 16 == 0, "bf16x3 needs 16-deep k-steps per K-group");
+  constexpr int SM = cmax(BF3 ? (ASH + BSH) : (AS + BSZ), KG * BM * (BN + 4));
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
   float* Bs = smem + AS;
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+  __bf16* Al = Ah + ASH;
+  __bf16* Bh = Al + ASH;
+  __bf16* Bl = Bh + BSH;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kg = wid >> 2, w4 = wid & 3;
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int row, c4;
-      tile_coord<A4>(tid + i * NT, row, c4);
+      if (BF3) { row = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, row, c4);
       float4 v = zero4();
       if (row < RA) {
         const int c = c0 + c4 * 4;
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int row, c4;
-      tile_coord<B4>(tid + i * NT, row, c4);
+      if (BF3) { row = (tid + i * NT) / B4; c4 = (tid + i * NT) % B4; } else tile_coord<B4>(tid + i * NT, row, c4);
       float4 v = zero4();
       if (row < BN) {
         const int n = n0 + row, e = c0 * KS + c4 * 4;
@@ -214,19 +236,44 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int row, c4;
-      tile_coord<A4>(tid + i * NT, row, c4);
+      if (BF3) { row = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, row, c4);
       if (row < RA) {
-        float* d = As + row * LDA + c4 * 4;
-        d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+        if (BF3) {
+          uint2 hi, lo;
+          split_bf16x4(ra.v[i], hi, lo);
+          *reinterpret_cast<uint2*>(Ah + row * LDAH + c4 * 4) = hi;
+          *reinterpret_cast<uint2*>(Al + row * LDAH + c4 * 4) = lo;
+        } else {
+          float* d = As + row * LDA + c4 * 4;
+          d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int row, c4;
-      tile_coord<B4>(tid + i * NT, row, c4);
+      if (BF3) { row = (tid + i * NT) / B4; c4 = (tid + i * NT) % B4; } else tile_coord<B4>(tid + i * NT, row, c4);
       if (row < BN) {
-        float* d = Bs + row * LDB + c4 * 4;
-        d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
+        if (BF3) {
+          uint2 hi, lo;
+          split_bf16x4(rb.v[i], hi, lo);
+          if (KS == 1) {
+            *reinterpret_cast<uint2*>(Bh + row * LDBH + c4 * 4) = hi;
+            *reinterpret_cast<uint2*>(Bl + row * LDBH + c4 * 4) = lo;
+          } else {                       // global order is (c, k) interleaved: scatter to the tap-major LDS row
+            const unsigned short h[4] = {(unsigned short)hi.x, (unsigned short)(hi.x >> 16), (unsigned short)hi.y, (unsigned short)(hi.y >> 16)};
+            const unsigned short l[4] = {(unsigned short)lo.x, (unsigned short)(lo.x >> 16), (unsigned short)lo.y, (unsigned short)(lo.y >> 16)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int e = c4 * 4 + j, cc_ = e / KS, kk_ = e % KS;
+              reinterpret_cast<unsigned short*>(Bh)[row * LDBH + kk_ * KC + cc_] = h[j];
+              reinterpret_cast<unsigned short*>(Bl)[row * LDBH + kk_ * KC + cc_] = l[j];
+            }
+          }
+        } else {
+          float* d = Bs + row * LDB + c4 * 4;
+          d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
+        }
       }
     }
   };
@@ -239,6 +286,37 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   AVDF_PROBE(1);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
+    if constexpr (BF3) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+#pragma unroll
+        for (int cc = 0; cc < KCG; cc += 16) {
+          bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int off = (((wm * MI + mi) * 32 + li) * S + k) * LDAH + kg * KCG + cc + lh * 8;
+            ah[mi] = *reinterpret_cast<const bf16x8*>(Ah + off);
+            al[mi] = *reinterpret_cast<const bf16x8*>(Al + off);
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int off = ((wn * NI + ni) * 32 + li) * LDBH + k * KC + kg * KCG + cc + lh * 8;
+            bh[ni] = *reinterpret_cast<const bf16x8*>(Bh + off);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              floatx16 c_ = acc[mi * NI + ni];
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], c_, 0, 0, 0);
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], c_, 0, 0, 0);
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], c_, 0, 0, 0);
+              acc[mi * NI + ni] = c_;
+            }
+        }
+      }
+    } else {
     const float* Ag = As + kg * KCG;
     const float* Bg = Bs + kg * KCG * KS;
 #pragma unroll
@@ -258,6 +336,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
           for (int ni = 0; ni < NI; ++ni)
             acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
       }
+    }
     }
     __syncthreads();
     AVDF_PROBE(2 + 2 * kt);
@@ -681,6 +760,9 @@ inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, 
     if (t->kind == kind && t->K == K && t->stride == stride && t->M == M && t->N == N && t->Kred == Kred) return t;
   return nullptr;
 }
+// GEMM arithmetic mode: 0 = exact fp32 MFMA (default, what the parity goldens are held against), 1 = split-bf16
+// ("bf16x3") operands in the forward kernels (experimental, avdf_gemm_mode)
+static int g_gemm_mode = [] { const char* e = getenv("AVDF_GEMM_MODE"); return e ? atoi(e) : 0; }();
 // process-wide override used by the tuner: g_override[kind] = {a, b}, -1 = off
 static int g_override[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
 
@@ -810,6 +892,14 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
     const int tilesT = cdiv(Tout, BM_);                                                                 \
     dim3 grid(B * tilesT, cdiv(Cout, BN_), nprob);                                                      \
+    if constexpr ((KC_ / KG_) % 16 == 0) {                                                              \
+      if (g_gemm_mode == 1) {                                                                           \
+        hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
+                           dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
+                           ldx, ldw, ldy);                                                              \
+        break;                                                                                          \
+      }                                                                                                 \
+    }                                                                                                   \
     hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy);          \
   } while (0)
@@ -1046,5 +1136,12 @@ extern "C" int avdf_gemm_override(int kind, int a, int b) {
   AVDF_REQUIRE(kind >= 0 && kind < 3, "gemm_override: kind in 0..2");
   g_override[kind][0] = a;
   g_override[kind][1] = b;
+  return AVDF_OK;
+}
+
+// 0 = exact fp32 MFMA (default); 1 = split-bf16 (bf16x3) operands in the forward conv GEMMs (experimental)
+extern "C" int avdf_gemm_mode(int mode) {
+  AVDF_REQUIRE(mode == 0 || mode == 1, "gemm_mode: 0 (fp32) or 1 (bf16x3 forward)");
+  g_gemm_mode = mode;
   return AVDF_OK;
 }

@@ -165,4 +165,6 @@ class AudioNTT2020Task6(nn.Module):
 def byola_features(pcm, model, frontend):
     """PCM [N] fp32 @16 kHz (device) -> [(1 + N // 160) // 8, 2048], the array the reference saves as .npy
     (extract_audio_feature_batch.py:104-123) before the dataset trims it (deepfake_video_audio.py:1683)."""
-    return model.forward_image(frontend(pcm))
+    lms = frontend(pcm)                      # STFT / mel GEMMs stay exact fp32: log() follows
+    with ops.infer_mode():
+        return model.forward_image(lms)

@@ -99,7 +99,8 @@ class C3DVideoEncoder(nn.Module):
                 x, H, W = y, H // pool, W // pool
         assert H * W == 4, (H, W)
         w1, b1 = self._packed[1]
-        return ops.linear(x.view(B * T, -1), w1, b1, ops.ACT_LEAKY).view(B, T, -1)
+        with ops.infer_mode():
+            return ops.linear(x.view(B * T, -1), w1, b1, ops.ACT_LEAKY).view(B, T, -1)
 
     @torch.no_grad()
     def forward(self, video):

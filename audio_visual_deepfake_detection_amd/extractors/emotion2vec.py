@@ -167,6 +167,10 @@ class Emotion2Vec(nn.Module):
     def forward_clip(self, pcm):
         """pcm [N] fp32 @16 kHz on the device -> [(N - 400) // 320 + 1, 768]."""
         assert not self.training and pcm.dim() == 1 and pcm.is_cuda
+        with ops.infer_mode():
+            return self._forward_clip(pcm)
+
+    def _forward_clip(self, pcm):
         enc = self.modality_encoders["AUDIO"]
         st = torch.cuda.current_stream().cuda_stream
         dev = pcm.device

@@ -43,7 +43,7 @@ class MaskedConv1D(nn.Module):
         if bias:
             torch.nn.init.constant_(self.conv.bias, 0.)
 
-    def forward(self, x, mask, act=ops.ACT_NONE):
+    def forward(self, x, mask, act=ops.ACT_NONE, exact=False):
         B, T, C = x.shape
         assert T % self.stride == 0            # blocks.py:46
         out_mask = downsample_mask(mask, self.stride)
@@ -51,7 +51,7 @@ class MaskedConv1D(nn.Module):
             assert self.conv.bias is None
             y = ops.dwconv(x, self.conv.weight, out_mask, self.stride)
         else:
-            y = ops.conv1d(x, self.conv.weight, self.conv.bias, out_mask, self.stride, act)
+            y = ops.conv1d(x, self.conv.weight, self.conv.bias, out_mask, self.stride, act, exact=exact)
         return y, out_mask
 
 
@@ -370,7 +370,7 @@ class DownBlock(nn.Module):
         assert norm, "every shipped config builds DownBlock with norm=True"
 
     def forward(self, x, mask):
-        x, mask = self.conv_block(x, mask)
+        x, mask = self.conv_block(x, mask, exact=True)      # feeds an InstanceNorm over time: keep the exact-fp32 GEMM
         return ops.instnorm_lrelu(x, 1e-5, 0.2), mask
 
 

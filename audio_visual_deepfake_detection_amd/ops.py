@@ -8,6 +8,7 @@ Layout: activations time-major [B, T, C] fp32; masks fp32 [B, T]; weights in the
 layouts (Conv1d [Cout, Cin/groups, K], LayerNorm [1, C, 1], ...).
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -207,7 +208,57 @@ class Conv1dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE):
+GEMM_MODE = 0        # forward conv GEMMs: 0 = exact fp32 MFMA, 1 = split-bf16 operands (bf16x3, ~5e-6 relative error)
+INFER_BF16X3 = True  # inference paths (model.eval(), InferStep, the frozen extractors) run their forward GEMMs in bf16x3
+
+
+def set_gemm_mode(mode):
+    """Process-wide arithmetic mode of the forward conv GEMMs (see avdf_gemm_mode)."""
+    global GEMM_MODE
+    GEMM_MODE = int(mode)
+    check(lib.avdf_gemm_mode(GEMM_MODE), "gemm_mode")
+
+
+class gemm_mode:
+    """with ops.gemm_mode(1): ...   -- forward conv GEMMs launched inside use the given arithmetic mode."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = GEMM_MODE
+        set_gemm_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        set_gemm_mode(self.prev)
+        return False
+
+
+def infer_mode():
+    """Arithmetic mode of the inference-only paths: bf16x3 unless disabled (INFER_BF16X3 / AVDF_GEMM_MODE=0)."""
+    return gemm_mode(1 if (INFER_BF16X3 and _os.environ.get("AVDF_GEMM_MODE", "") != "0") else GEMM_MODE)
+
+
+class _ExactGemm:
+    """Force the exact-fp32 forward GEMM for the launches inside the block (launch-time host switch)."""
+
+    def __enter__(self):
+        if GEMM_MODE != 0:
+            lib.avdf_gemm_mode(0)
+
+    def __exit__(self, *a):
+        if GEMM_MODE != 0:
+            lib.avdf_gemm_mode(GEMM_MODE)
+        return False
+
+
+def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE, exact=False):
+    """exact=True keeps the exact-fp32 MFMA even in bf16x3 mode: used where the output feeds an InstanceNorm over
+    time, which can amplify rounding differences of near-constant channels by 1/sqrt(var + eps) ~ 300."""
+    if exact:
+        with _ExactGemm():
+            return Conv1dFn.apply(x, w, bias, mask, stride, act)
     return Conv1dFn.apply(x, w, bias, mask, stride, act)
 
 
@@ -1043,3 +1094,8 @@ def decode_nms(points, logits, offsets, pmask, pre_nms_thresh, duration_thresh, 
                               _p(pidx), _p(count), B, P, pre_nms_thresh, duration_thresh, min_score, iou_thr,
                               voting_thr, max_seg, _stream()), "decode_nms")
     return segs, scores, pidx, count
+
+
+# package default: exact fp32 everywhere in training; AVDF_GEMM_MODE=1 switches the training forward GEMMs to bf16x3 too,
+# AVDF_GEMM_MODE=0 also pins the inference paths to exact fp32
+set_gemm_mode(int(_os.environ.get("AVDF_GEMM_MODE", GEMM_MODE)))

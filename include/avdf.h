@@ -62,6 +62,11 @@ int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* c
  * (token splits, K-groups)); a = -1 restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only. */
 int avdf_gemm_override(int kind, int a, int b);
 
+/* Arithmetic mode of the forward conv GEMMs: 0 = exact fp32 MFMA (default; what the parity fixtures are held
+ * against), 1 = split-bf16 operands ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate,
+ * ~2^-17 relative error per product).  Experimental.                                                          */
+int avdf_gemm_mode(int mode);
+
 /* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the
  * wav2vec2 feature extractor, fairseq ConvFeatureExtractionModel named at audio_feature/emotion_audio/upstream/
  * models/audio.py:12-17,66-71) and explicit row strides (floats), so x / w / y may be column slices of wider

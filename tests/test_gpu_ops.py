@@ -475,3 +475,21 @@ def test_interp_batched_equals_per_clip(ops):
     ops.interp_concat_batched(bufs, out)
     for b in range(3):
         assert torch.equal(out[b], ops.interp_concat([s[b] for s in bufs], 96))
+
+
+@pytest.mark.parametrize("case", [(2, 96, 40, 32, 3, 1), (2, 72, 256, 256, 1, 1), (6, 768, 64, 256, 3, 1), (3, 96, 64, 36, 3, 2),
+                                  (8, 768, 256, 1024, 1, 1), (1, 24, 2048, 256, 3, 2)])
+def test_conv1d_forward_bf16x3_mode(ops, case):
+    """Split-bf16 (hi*hi + hi*lo + lo*hi) forward GEMM of the inference paths: fp32-grade result (~5e-6 of the output
+    scale) from the bf16 matrix cores; the default mode outside `ops.gemm_mode(1)` stays exact fp32."""
+    B, T, Cin, Cout, K, s = case
+    x, w, b = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, K, seed=2, scale=(Cin * K) ** -0.5), rnd(Cout, seed=3)
+    ref = F.conv1d(x.transpose(1, 2), w, b, s, K // 2).transpose(1, 2)
+    assert ops.GEMM_MODE == 0
+    with ops.gemm_mode(1):
+        y1 = ops.conv1d(g32(x), g32(w), g32(b), None, s)
+    assert ops.GEMM_MODE == 0
+    y0 = ops.conv1d(g32(x), g32(w), g32(b), None, s)
+    close(y1, ref, "bf16x3 conv fwd", rtol=2e-5)
+    close(y0, ref, "fp32 conv fwd", rtol=2e-6 if Cin * K < 4096 else 5e-6)
+    # (plans whose K-group slice is not a multiple of 16 keep the exact kernel even in mode 1, so y0 may equal y1)
