@@ -88,6 +88,7 @@ SIGNATURES = {
     "avdf_chain_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "avdf_reduce_segments": (I, [P, I, I, I, P, P, P, P, I, P]),
     "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "avdf_conv3d_mode": (I, [I]),
     "avdf_video_prep": (I, [P, P, I, I, I, I, I, P]),
     "avdf_maxpool_hw": (I, [P, P, L, I, I, I, I, P]),
     "avdf_softmax_alibi": (I, [P, I, I, F, F, P]),

@@ -21,7 +21,18 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 template <int N>
 struct F4Buf { float4 v[N]; };
 
-template <int TT, int TH, int TW, int WM, int WN, int MI, int NI, int KC>
+// split-bf16 operands (see gemm_conv.hip): x = hi + lo, a*b ~ hi*hi + hi*lo + lo*hi on the bf16 matrix cores
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo) {
+  const __bf16 h0 = (__bf16)v.x, h1 = (__bf16)v.y, h2 = (__bf16)v.z, h3 = (__bf16)v.w;
+  const __bf16 l0 = (__bf16)(v.x - (float)h0), l1 = (__bf16)(v.y - (float)h1), l2 = (__bf16)(v.z - (float)h2),
+               l3 = (__bf16)(v.w - (float)h3);
+  hi.x = bf16_bits(h0) | ((unsigned)bf16_bits(h1) << 16); hi.y = bf16_bits(h2) | ((unsigned)bf16_bits(h3) << 16);
+  lo.x = bf16_bits(l0) | ((unsigned)bf16_bits(l1) << 16); lo.y = bf16_bits(l2) | ((unsigned)bf16_bits(l3) << 16);
+}
+
+template <int TT, int TH, int TW, int WM, int WN, int MI, int NI, int KC, bool BF3 = false>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     int B, int T, int H, int W, int Cin, int Cout, int act, int tilesT, int tilesH, int tilesW) {
@@ -34,9 +45,18 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   constexpr int A4 = KC / 4;
   constexpr int NA = (HV * A4 + 255) / 256, NB = (9 * BN * A4 + 255) / 256;
   constexpr int AS = (HV * LDA + 3) / 4 * 4;
-  __shared__ __attribute__((aligned(16))) float smem[AS + 9 * BN * LDB];
+  // BF3: hi / lo bf16 planes, rows padded by 8 elements (conflict-free 16-byte fragment reads)
+  constexpr int LDH = KC + 8;
+  constexpr int ASH = HV * LDH, BSH = 9 * BN * LDH;
+  static_assert(!BF3 || KC % 16 == 0, "bf16x3 needs 16-deep channel chunks");
+  constexpr int SMF = BF3 ? (ASH + BSH) : (AS + 9 * BN * LDB);
+  __shared__ __attribute__((aligned(16))) float smem[SMF];
   float* As = smem;
   float* Bs = smem + AS;
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+  __bf16* Al = Ah + ASH;
+  __bf16* Bh = Al + ASH;
+  __bf16* Bl = Bh + BSH;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -61,7 +81,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   for (int mi = 0; mi < MI; ++mi) {
     const int m = (wm * MI + mi) * 32 + li;
     const int pt = m / (TH * TW), ph = (m / TW) % TH, pw = m % TW;
-    abase[mi] = ((pt * HH + ph) * HW + pw) * LDA + lh;
+    abase[mi] = ((pt * HH + ph) * HW + pw) * (BF3 ? LDH : LDA) + (BF3 ? lh * 8 : lh);
   }
 
   F4Buf<NA> ra;
@@ -100,16 +120,30 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
     for (int i = 0; i < NA; ++i) {
       const int q = tid + i * 256;
       if (q < HV * A4) {
-        float* d = As + (q / A4) * LDA + (q % A4) * 4;
-        d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+        if (BF3) {
+          uint2 hi, lo;
+          split_bf16x4(ra.v[i], hi, lo);
+          *reinterpret_cast<uint2*>(Ah + (q / A4) * LDH + (q % A4) * 4) = hi;
+          *reinterpret_cast<uint2*>(Al + (q / A4) * LDH + (q % A4) * 4) = lo;
+        } else {
+          float* d = As + (q / A4) * LDA + (q % A4) * 4;
+          d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int q = tid + i * 256;
       if (q < 9 * BN * A4) {
-        float* d = Bs + (q / A4) * LDB + (q % A4) * 4;
-        d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
+        if (BF3) {
+          uint2 hi, lo;
+          split_bf16x4(rb.v[i], hi, lo);
+          *reinterpret_cast<uint2*>(Bh + (q / A4) * LDH + (q % A4) * 4) = hi;
+          *reinterpret_cast<uint2*>(Bl + (q / A4) * LDH + (q % A4) * 4) = lo;
+        } else {
+          float* d = Bs + (q / A4) * LDB + (q % A4) * 4;
+          d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
+        }
       }
     }
   };
@@ -119,6 +153,37 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   __syncthreads();
   for (int s = 0; s < nstage; ++s) {
     if (s + 1 < nstage) load_stage(s + 1);
+    if constexpr (BF3) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int aoff = ((tap / 3) * HW + (tap % 3)) * LDH;
+#pragma unroll
+        for (int cc = 0; cc < KC; cc += 16) {
+          bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            ah[mi] = *reinterpret_cast<const bf16x8*>(Ah + abase[mi] + aoff + cc);
+            al[mi] = *reinterpret_cast<const bf16x8*>(Al + abase[mi] + aoff + cc);
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int off = (tap * BN + (wn * NI + ni) * 32 + li) * LDH + cc + lh * 8;
+            bh[ni] = *reinterpret_cast<const bf16x8*>(Bh + off);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              floatx16 c_ = acc[mi * NI + ni];
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], c_, 0, 0, 0);
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], c_, 0, 0, 0);
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], c_, 0, 0, 0);
+              acc[mi * NI + ni] = c_;
+            }
+        }
+      }
+    } else {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int aoff = ((tap / 3) * HW + (tap % 3)) * LDA;
@@ -135,6 +200,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
           for (int ni = 0; ni < NI; ++ni)
             acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
       }
+    }
     }
     __syncthreads();
     if (s + 1 < nstage) {
@@ -208,6 +274,13 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+static int g_c3d_mode = 0;      // 0 exact fp32 MFMA, 1 split-bf16 operands (layers with Cin >= 16)
+extern "C" int avdf_conv3d_mode(int mode) {
+  AVDF_REQUIRE(mode == 0 || mode == 1, "conv3d_mode: 0 (fp32) or 1 (bf16x3)");
+  g_c3d_mode = mode;
+  return AVDF_OK;
+}
+
 extern "C" int avdf_conv3d_k3(const float* x, const float* wp, const float* bias, float* y, int B, int T, int H, int W,
                               int Cin, int Cout, int act, void* stream) {
   AVDF_REQUIRE(x && wp && y, "conv3d_k3: null pointer");
@@ -222,6 +295,14 @@ extern "C" int avdf_conv3d_k3(const float* x, const float* wp, const float* bias
     const int tT = cdiv(T, TT_), tH = cdiv(H, TH_), tW = cdiv(W, TW_);                                             \
     const int64_t nblk = (int64_t)B * tT * tH * tW;                                                                \
     AVDF_REQUIRE(nblk < ((int64_t)1 << 31), "conv3d_k3: grid too large");                                          \
+    if constexpr (KC_ % 16 == 0) {                                                                                 \
+      if (g_c3d_mode == 1) {                                                                                       \
+        hipLaunchKernelGGL((conv3d_k3_kernel<TT_, TH_, TW_, WM_, WN_, MI_, NI_, KC_, true>),                       \
+                           dim3((unsigned)nblk, cdiv(Cout, BN_)), dim3(256), 0, st, x, wp, bias, y, B, T, H, W,    \
+                           Cin, Cout, act, tT, tH, tW);                                                            \
+        break;                                                                                                     \
+      }                                                                                                            \
+    }                                                                                                              \
     hipLaunchKernelGGL((conv3d_k3_kernel<TT_, TH_, TW_, WM_, WN_, MI_, NI_, KC_>), dim3((unsigned)nblk, cdiv(Cout, BN_)), \
                        dim3(256), 0, st, x, wp, bias, y, B, T, H, W, Cin, Cout, act, tT, tH, tW);                  \
   } while (0)

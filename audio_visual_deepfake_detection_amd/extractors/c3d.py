@@ -13,6 +13,8 @@ Exact tail trimming: a chunk's padding frames are zeros, and each of the 8 convs
 [0, L) of the last chunk depend only on input frames [0, L+8): the last chunk is computed on min(512, L+8) frames
 (bit-identical rows, ~25% less work on a 768-frame clip).  `trim_tail=False` restores the full 512-frame chunk.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -87,6 +89,8 @@ class C3DVideoEncoder(nn.Module):
         st = torch.cuda.current_stream().cuda_stream
         B, T, H, W, _ = x.shape
         assert H == W and H % 48 == 0, "the pooling chain (3,2,2,2,2) must end at 2x2"
+        bf3 = 1 if (ops.INFER_BF16X3 and os.environ.get("AVDF_GEMM_MODE", "") != "0") else 0
+        check(lib.avdf_conv3d_mode(bf3), "conv3d_mode")          # split-bf16 operands for the Cin >= 16 layers
         for (wp, b), (_, pool) in zip(self._packed[0], self._plan):
             cout, cin = wp.shape[3], wp.shape[4]
             y = torch.empty((B, T, H, W, cout), dtype=torch.float32, device=x.device)
@@ -97,6 +101,7 @@ class C3DVideoEncoder(nn.Module):
                 y = torch.empty((B, T, H // pool, W // pool, cout), dtype=torch.float32, device=x.device)
                 check(lib.avdf_maxpool_hw(x.data_ptr(), y.data_ptr(), B * T, H, W, cout, pool, st), "maxpool_hw")
                 x, H, W = y, H // pool, W // pool
+        check(lib.avdf_conv3d_mode(0), "conv3d_mode")
         assert H * W == 4, (H, W)
         w1, b1 = self._packed[1]
         with ops.infer_mode():

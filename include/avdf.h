@@ -317,6 +317,8 @@ int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, fl
  * packed once from the reference [Cout, Cin, 3, 3, 3]).                                                  */
 int avdf_conv3d_k3(const float* x, const float* wp, const float* bias, float* y, int B, int T, int H, int W,
                    int Cin, int Cout, int act, void* stream);
+/* 0 = exact fp32 MFMA (default), 1 = split-bf16 operands for the layers with Cin >= 16 (~5e-6 relative error) */
+int avdf_conv3d_mode(int mode);
 /* uint8 frames [T, H0, W0, 3] -> fp32 [Tp, S, S, 4] (/255, nearest resize, 4th channel and frames >= T zero) */
 int avdf_video_prep(const uint8_t* frames, float* out, int T, int H0, int W0, int Tp, int S, void* stream);
 /* [N, H, W, C] -> [N, H/p, W/p, C] max over p x p windows (floor mode) */
