@@ -18,6 +18,8 @@ SIGNATURES = {
     "avdf_version": (I, []),
     "avdf_conv1d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_fwd_ex": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "avdf_conv1d_fwd_strided": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, L, L, L, I, P]),
+    "avdf_softmax_alibi_heads": (I, [P, I, I, I, L, F, P, P]),
     "avdf_gemm_mode": (I, [I]),
     "avdf_gemm_override": (I, [I, I, I]),
     "avdf_conv1d_fwd_grouped": (I, [I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

@@ -74,11 +74,14 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(const float* __restri
 }
 
 // in place: P[i, j] = softmax_j( S[i, j]*qk_scale - slope * |i - j| ) for j < T, 0 for T <= j < ld.  One wave per row.
-__global__ __launch_bounds__(256) void softmax_alibi_kernel(float* __restrict__ s, int T, int ld, float qk_scale, float slope) {
+__global__ __launch_bounds__(256) void softmax_alibi_kernel(float* __restrict__ s, int T, int ld, float qk_scale,
+                                                            const float* __restrict__ slopes, float slope, long hstride) {
+  // blockIdx.y = head: scores + head*hstride, slope = slopes[head] (or the scalar when slopes == NULL)
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= T) return;
-  float* row = s + (size_t)i * ld;
+  if (slopes) slope = slopes[blockIdx.y];
+  float* row = s + (size_t)blockIdx.y * hstride + (size_t)i * ld;
   float m = -INFINITY;
   for (int j = lane; j < T; j += 64) {
     const float v = row[j] * qk_scale - slope * fabsf((float)(i - j));
@@ -128,7 +131,18 @@ extern "C" int avdf_grouped_conv_pos(const float* x, const float* w, const float
 
 extern "C" int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream) {
   AVDF_REQUIRE(scores && T > 0 && ld >= T, "softmax_alibi: bad args");
-  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, scores, T, ld, qk_scale, slope);
+  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, scores, T, ld, qk_scale,
+                     (const float*)nullptr, slope, 0L);
   AVDF_CHECK_LAUNCH("softmax_alibi");
+  return AVDF_OK;
+}
+
+// all heads of a layer in one launch: scores [H][T][ld] (head stride in floats), slopes [H] on the device
+extern "C" int avdf_softmax_alibi_heads(float* scores, int H, int T, int ld, int64_t head_stride, float qk_scale,
+                                        const float* slopes, void* stream) {
+  AVDF_REQUIRE(scores && slopes && H > 0 && T > 0 && ld >= T && head_stride >= (int64_t)T * ld, "softmax_alibi_heads: bad args");
+  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv(T, 4), H), dim3(256), 0, (hipStream_t)stream, scores, T, ld, qk_scale,
+                     slopes, 0.f, (long)head_stride);
+  AVDF_CHECK_LAUNCH("softmax_alibi_heads");
   return AVDF_OK;
 }

@@ -156,7 +156,10 @@ __device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0
 // ------------------------------------------------------------------------------------------
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3 = false>
 __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
-    FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy) {
+    FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy,
+    long xbs, long wbs, long ybs) {
+  // xbs / wbs / ybs: batch strides of x, w, y in floats (default Tin*ldx, 0, Tout*ldy; attention heads use
+  // column-slice strides and one weight matrix -- the K or V^T slice -- per batch entry)
   const int prob = blockIdx.z;
   const float* __restrict__ x = pick3(ptrs.x, prob);
   const float* __restrict__ w = pick3(ptrs.w, prob);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       if (row < RA) {
         const int c = c0 + c4 * 4;
         const int tr = t0 * S - P + row;
-        if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + tr) * ldx + c);
+        if (tr >= 0 && tr < Tin && c < Cin) v = ld4(x + (size_t)b * xbs + (size_t)tr * ldx + c);
       }
       ra.v[i] = v;
     }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       float4 v = zero4();
       if (row < BN) {
         const int n = n0 + row, e = c0 * KS + c4 * 4;
-        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * ldw + e);
+        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)b * wbs + (size_t)n * ldw + e);
       }
       rb.v[i] = v;
     }
@@ -347,26 +350,27 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
     AVDF_PROBE(3 + 2 * kt);
   }
   AVDF_PROBE(14);
-  const bool vec = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+  const bool vec = ((ldy & 3) == 0) && ((ybs & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                    (ypre == nullptr || (reinterpret_cast<uintptr_t>(ypre) & 15) == 0);
   tile_epilogue<BM, BN, KG, WN, MI, NI>(acc, smem, kg, wm, wn, li, lh, tid, [&](int row_, int c, float4 v) {
     const int t = t0 + row_, n = n0 + c;
     if (t >= Tout || n >= Cout) return;
     const size_t row = (size_t)b * Tout + t;
+    const size_t yrow = (size_t)b * ybs + (size_t)t * ldy;
     const float m = mask ? mask[row] : 1.f;
     if (vec && n + 3 < Cout) {
       if (bias) { const float4 bb = ld4(bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-      if (ypre) *reinterpret_cast<float4*>(ypre + row * ldy + n) = v;
+      if (ypre) *reinterpret_cast<float4*>(ypre + yrow + n) = v;
       v.x = act_f(v.x, act) * m; v.y = act_f(v.y, act) * m; v.z = act_f(v.z, act) * m; v.w = act_f(v.w, act) * m;
-      *reinterpret_cast<float4*>(y + row * ldy + n) = v;
+      *reinterpret_cast<float4*>(y + yrow + n) = v;
     } else {
       const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (n + j >= Cout) break;
         float u = e[j] + (bias ? bias[n + j] : 0.f);
-        if (ypre) ypre[row * ldy + n + j] = u;
-        y[row * ldy + n + j] = act_f(u, act) * m;
+        if (ypre) ypre[yrow + n + j] = u;
+        y[yrow + n + j] = act_f(u, act) * m;
       }
     }
   });
@@ -885,7 +889,10 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
   }
 
 static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
-                             int stride, int pad, int ldx, int ldw, int ldy, int act, hipStream_t st) {
+                             int stride, int pad, int ldx, int ldw, int ldy, int act, hipStream_t st, long xbs = -1,
+                             long wbs = 0, long ybs = -1) {
+  if (xbs < 0) xbs = (long)Tin * ldx;
+  if (ybs < 0) ybs = (long)Tout * ldy;
   const TilePlan plan = pick_tile(B * nprob, Tout, Cout, false, K, stride, Cin);
 #define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
   do {                                                                                                  \
@@ -896,12 +903,13 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
       if (g_gemm_mode == 1) {                                                                           \
         hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
                            dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
-                           ldx, ldw, ldy);                                                              \
+                           ldx, ldw, ldy, xbs, wbs, ybs);                                               \
         break;                                                                                          \
       }                                                                                                 \
     }                                                                                                   \
     hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
-                       0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy);          \
+                       0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy, xbs, wbs, \
+                       ybs);                                                                            \
   } while (0)
   if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, LAUNCH_FWD) }
   else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, LAUNCH_FWD) }
@@ -988,6 +996,24 @@ static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin,
 #undef LAUNCH_DG
   AVDF_CHECK_LAUNCH("conv1d_bwd_data");
   return AVDF_OK;
+}
+
+// avdf_conv1d_fwd_ex with explicit batch strides (floats): batch b reads x + b*xbs, uses the weight matrix w + b*wbs
+// and writes y + b*ybs -- all the heads of an attention layer (Q_h.K_h^T or P_h.V_h^T) in ONE launch.
+extern "C" int avdf_conv1d_fwd_strided(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Cin,
+                                       int Tout, int Cout, int K, int stride, int pad, int ldx, int ldw, int ldy,
+                                       int64_t xbs, int64_t wbs, int64_t ybs, int act, void* stream) {
+  AVDF_REQUIRE(x && w && y, "conv1d_fwd_strided: null pointer");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0 && pad >= 0, "conv1d_fwd_strided: bad dims");
+  AVDF_REQUIRE((K == 1 && stride == 1) || (K == 2 && stride == 2) || (K == 3 && (stride == 1 || stride == 2)),
+               "conv1d_fwd_strided: unsupported (K=%d, stride=%d)", K, stride);
+  AVDF_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ldx >= Cin && ldw >= Cin * K && ldy >= Cout &&
+                   xbs % 4 == 0 && wbs % 4 == 0 && xbs >= 0 && wbs >= 0 && ybs >= 0,
+               "conv1d_fwd_strided: Cin / ld / batch strides must be non-negative multiples of 4 and cover the operands");
+  AVDF_REQUIRE(Tout == (Tin + 2 * pad - K) / stride + 1, "conv1d_fwd_strided: Tout=%d inconsistent", Tout);
+  AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd_strided: x/w must be 16-byte aligned");
+  return conv1d_fwd_launch(fwd_ptrs1(x, w, bias, nullptr, y, nullptr), 1, B, Tin, Cin, Tout, Cout, K, stride, pad, ldx,
+                           ldw, ldy, act, (hipStream_t)stream, (long)xbs, (long)wbs, (long)ybs);
 }
 
 extern "C" int avdf_conv1d_bwd_data(const float* dy, const float* w, const float* mask, const float* ypre,

@@ -125,7 +125,9 @@ class Emotion2Vec(nn.Module):
         return ops.linear(x, lin.weight, lin.bias, act)
 
     def _attention(self, x, attn, T, layer):
-        """AltAttention.forward (modules.py:280-322) for one clip; x [Tp, D] (rows >= T are padding)."""
+        """AltAttention.forward (modules.py:280-322) for one clip; x [Tp, D] (rows >= T are padding).  All heads of a
+        layer run as ONE launch per step (batch-strided GEMMs: head h = column slice h*hd of q / k / out, its own
+        V^T rows as the weight matrix)."""
         Tp, D = x.shape
         H, hd = self.heads, D // self.heads
         st = torch.cuda.current_stream().cuda_stream
@@ -134,24 +136,23 @@ class Emotion2Vec(nn.Module):
         k = ops.linear(x, w[D:2 * D], b[D:2 * D])
         v = ops.linear(x, w[2 * D:3 * D], b[2 * D:3 * D])
         vT = ops.transpose_last2(v.view(1, Tp, D))[0]                       # [D, Tp]
-        scores = torch.empty((Tp, Tp), dtype=torch.float32, device=x.device)
+        scores = torch.empty((H, Tp, Tp), dtype=torch.float32, device=x.device)
         out = torch.zeros((Tp, D), dtype=torch.float32, device=x.device)
         enc = self.modality_encoders["AUDIO"]
-        sc = None
         if enc.alibi_scale is not None:
             a = enc.alibi_scale.clamp_min(0)
             sc = (a[layer] if a.shape[0] > 1 else a[0]).reshape(-1)       # [H] or [1]
-            sc = (self._slopes * sc).tolist()
-        for h in range(H):
-            qh = q.data_ptr() + h * hd * 4
-            kh = k.data_ptr() + h * hd * 4
-            check(lib.avdf_conv1d_fwd_ex(qh, kh, None, scores.data_ptr(), 1, T, hd, T, T, 1, 1, 0, D, D, Tp, 0, st),
-                  "attn QK^T")
-            check(lib.avdf_softmax_alibi(scores.data_ptr(), T, Tp, hd ** -0.5, 0.0 if sc is None else float(sc[h]), st),
-                  "softmax_alibi")
-            check(lib.avdf_conv1d_fwd_ex(scores.data_ptr(), vT.data_ptr() + h * hd * Tp * 4, None,
-                                         out.data_ptr() + h * hd * 4, 1, T, Tp, T, hd, 1, 1, 0, Tp, Tp, D, 0, st),
-                  "attn PV")
+            slopes = (self._slopes * sc).contiguous()
+        else:
+            slopes = torch.zeros(H, dtype=torch.float32, device=x.device)
+        # S_h = Q_h K_h^T: batch = head, x = q + h*hd (row stride D), "weights" = k + h*hd, y = scores[h]
+        check(lib.avdf_conv1d_fwd_strided(q.data_ptr(), k.data_ptr(), None, scores.data_ptr(), H, T, hd, T, T, 1, 1, 0, D, D, Tp,
+                                          hd, hd, Tp * Tp, 0, st), "attn QK^T")
+        check(lib.avdf_softmax_alibi_heads(scores.data_ptr(), H, T, Tp, Tp * Tp, hd ** -0.5, slopes.data_ptr(), st),
+              "softmax_alibi_heads")
+        # O_h = P_h V_h: x = scores[h] (K = Tp), weights = V^T rows h*hd.. (row stride Tp), y = out + h*hd
+        check(lib.avdf_conv1d_fwd_strided(scores.data_ptr(), vT.data_ptr(), None, out.data_ptr(), H, T, Tp, T, hd, 1, 1, 0, Tp, Tp, D,
+                                          Tp * Tp, hd * Tp, hd, 0, st), "attn PV")
         return self._linear(out, attn.proj)
 
     def _block(self, x, blk, T, layer):

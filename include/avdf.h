@@ -62,6 +62,13 @@ int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* c
  * (token splits, K-groups)); a = -1 restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only. */
 int avdf_gemm_override(int kind, int a, int b);
 
+/* avdf_conv1d_fwd_ex with explicit batch strides (floats): batch b reads x + b*xbs, multiplies by the weight matrix
+ * w + b*wbs and writes y + b*ybs -- every head of an attention layer (Q_h.K_h^T, P_h.V_h^T) in one launch
+ * (AltAttention.forward, audio_feature/emotion_audio/upstream/models/modules.py:303-316).                        */
+int avdf_conv1d_fwd_strided(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Cin,
+                            int Tout, int Cout, int K, int stride, int pad, int ldx, int ldw, int ldy,
+                            int64_t xbs, int64_t wbs, int64_t ybs, int act, void* stream);
+
 /* Arithmetic mode of the forward conv GEMMs: 0 = exact fp32 MFMA (default; what the parity fixtures are held
  * against), 1 = split-bf16 operands ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate,
  * ~2^-17 relative error per product).  Experimental.                                                          */
@@ -270,6 +277,9 @@ int avdf_wave_conv_c1(const float* pcm, const float* w, float* y, int64_t n_samp
 int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, float* y, int T, int C,
                           int groups, int K, void* stream);
 int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream);
+/* all H heads of a layer in one launch: scores [H][T][ld] with `head_stride` floats between heads, slopes [H] (device) */
+int avdf_softmax_alibi_heads(float* scores, int H, int T, int ld, int64_t head_stride, float qk_scale,
+                             const float* slopes, void* stream);
 
 /* ---- fused AffineDropPath residual + LayerNorm (TransformerBlock: blocks.py:1311-1313, 870-872) ------------
  *   out = a*ma[b,t] + scale[c]*keep[b]*(r*mr[b,t]);  h = LN(out)*gamma + beta  (ma / mr / keep may be NULL)
