@@ -191,6 +191,9 @@ class TrainStep:
         """Warm up eagerly on a side stream (allocator, lazy init), then capture the three graphs."""
         if not self.use_graph:
             return
+        # the warm-up passes execute real forward / backward work: training state they touch (the EMA of the positive
+        # count that normalises the losses, av_fd_no_recon.py:645-648) is restored afterwards, so capture() is invisible
+        norm_state = self.model._loss_norm_state.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -200,6 +203,7 @@ class TrainStep:
                 self._outs = None
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self.model._loss_norm_state.copy_(norm_state)
         pool = torch.cuda.graph_pool_handle()
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga, pool=pool):

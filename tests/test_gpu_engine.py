@@ -1,0 +1,113 @@
+"""engine.TrainStep / InferStep (flat buffers, hipGraphs, fused optimiser) against the plain `model(video_list)` path."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(video_input_dim=8, audio_input_dim=88, max_seq_len=192, embd_dim=32, fpn_dim=32, head_dim=32, n_head=4)
+STREAMS = [(192, 8), (96, 64), (383, 24)]
+
+
+def _model(seed=0):
+    from audio_visual_deepfake_detection_amd import build_model
+    torch.manual_seed(seed)
+    model, cfg = build_model("deepfake_exp10.yaml", **SMALL)
+    model = model.to("cuda:0")
+    for mod in model.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    model.interpolator.dp1.p = 0.0
+    return model, cfg
+
+
+def _fill(eng, seed, all_real=False):
+    g = torch.Generator().manual_seed(seed)
+    clips = []
+    for b in range(eng.B):
+        ss = [torch.randn(shp, generator=g) for shp in STREAMS]
+        for dst, src in zip(eng.streams[b], ss):
+            dst.copy_(src)
+        segs = None
+        if b % 2 == 0 and not all_real:
+            segs = torch.tensor([[20.0 + 7 * b, 60.0 + 5 * b], [100.0, 118.0]])
+        if hasattr(eng, "gt"):
+            eng.gt[b].zero_()
+            eng.ngt[b] = 0 if segs is None else len(segs)
+            if segs is not None:
+                eng.gt[b, :len(segs)].copy_(segs)
+        clips.append(dict(video_id=f"c{b}", streams=[s.numpy() for s in ss], crop=None, segments=segs,
+                          labels=None if segs is None else torch.zeros(len(segs), dtype=torch.int64), fps=25.0,
+                          duration=192 / 25.0, feat_stride=1.0, feat_num_frames=1.0))
+    return clips
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_equals_plain_model_path(use_graph):
+    from audio_visual_deepfake_detection_amd.engine import TrainStep
+    model, cfg = _model(1)
+    ref = copy.deepcopy(model).train()
+    eng = TrainStep(model, 4, STREAMS, lr=1e-3, weight_decay=0.05, clip_grad_l2norm=1.0, use_graph=use_graph)
+    clips = _fill(eng, 5)
+    eng.capture()
+    eng.step()
+    got = eng.losses()
+    losses = ref(clips)
+    losses["final_loss"].backward()
+    for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss"):
+        assert abs(got[k] - float(losses[k])) < 2e-5 * max(1.0, abs(float(losses[k]))), (k, got[k], float(losses[k]))
+    # one fused step == clip_grad_norm_ + torch.optim.AdamW (decay / no-decay groups of make_optimizer) + EMA 0.999
+    from audio_visual_deepfake_detection_amd.engine import split_decay
+    named = dict(ref.named_parameters())
+    live = [n for n, p in named.items() if p.grad is not None]
+    decay, no_decay = split_decay(ref)
+    torch.nn.utils.clip_grad_norm_([named[n] for n in live], 1.0)
+    opt = torch.optim.AdamW([{"params": [named[n] for n in decay if n in live], "weight_decay": 0.05},
+                             {"params": [named[n] for n in no_decay if n in live], "weight_decay": 0.0}], lr=1e-3)
+    before = {n: named[n].detach().clone() for n in live}
+    opt.step()
+    new = dict(model.named_parameters())
+    ema = eng.ema_state_dict()
+    worst = 0.0
+    for n in live:
+        upd_ref, upd_got = named[n].detach() - before[n], new[n].detach() - before[n]
+        scale = float(upd_ref.abs().max()) + 1e-12
+        if float(named[n].grad.abs().max()) < 1e-7:
+            continue        # mathematically zero gradients (key bias under softmax, conv bias under InstanceNorm): Adam
+                            # turns their rounding noise into +-lr steps in either implementation
+        worst = max(worst, float((upd_got - upd_ref).abs().max()) / scale)
+        e_ref = 0.999 * before[n] + 0.001 * named[n].detach()
+        assert float((ema[n] - e_ref).abs().max()) <= 1e-6 * (1.0 + float(e_ref.abs().max())), n
+    assert worst < 2e-2, worst            # Adam's first step is ~lr*sign(g): elements with |g| near eps differ visibly
+
+
+def test_all_real_batch_has_no_positive_points_and_stays_finite():
+    from audio_visual_deepfake_detection_amd.engine import TrainStep
+    model, _ = _model(2)
+    eng = TrainStep(model, 2, STREAMS, use_graph=True)
+    _fill(eng, 6, all_real=True)
+    eng.capture()
+    for _ in range(2):
+        eng.step()
+    out = eng.losses()
+    assert out["num_pos"] == 0.0 and out["reg_loss"] == 0.0
+    assert all(np.isfinite(v) for v in out.values())
+    assert torch.isfinite(eng.flat_p).all()
+
+
+def test_infer_step_equals_eval_model():
+    from audio_visual_deepfake_detection_amd.engine import InferStep
+    model, _ = _model(3)
+    model.allow_batched_eval = True
+    eng = InferStep(model, 3, STREAMS, use_graph=True)
+    clips = _fill(eng, 7)
+    eng.capture()
+    segs, scores, pidx, count, cls_scores = eng.step()
+    for b, clip in enumerate(clips):
+        res = model.eval()([clip])[0]
+        n = int(count[b])
+        assert n == res["segments"].shape[0]
+        assert sorted(pidx[b, :n].tolist()) == sorted(res["kept_points"].tolist())
+        assert torch.allclose(scores[b, :n].cpu().sort().values, res["scores"].sort().values, atol=1e-5)
