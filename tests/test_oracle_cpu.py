@@ -1,0 +1,101 @@
+"""CPU: the oracle (oracle/ummaformer_ref.py, the checker of every GPU parity test) against the golden vectors the REAL
+reference produced (tests/golden/*.npz, oracle/make_golden.py) -- this is what pins the oracle.  No HIP involved."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ummaformer_ref as R
+
+SMALL = dict(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, head_dim=32)
+MID = dict(input_dim=192, max_seq_len=384, embd_dim=128, n_head=4, fpn_dim=128, head_dim=128)
+
+
+def synth_inputs(cfg, lens, seed):
+    rs = np.random.RandomState(seed)
+    B, C, T = len(lens), cfg["input_dim"], cfg["max_seq_len"]
+    x = np.zeros((B, C, T), dtype=np.float32)
+    for b, n in enumerate(lens):
+        x[b, :, :n] = rs.standard_normal((C, n)).astype(np.float32)
+    return torch.from_numpy(x)
+
+
+@pytest.mark.parametrize("name,over", [("fwd_small", SMALL), ("fwd_small_init", SMALL), ("fwd_mid", MID),
+                                       ("fwd_the_small", dict(variant="the", **SMALL)),
+                                       ("fwd_recon_small", dict(variant="recon", **SMALL)), ("fwd_exp10", {})])
+def test_oracle_forward_and_detections_match_reference(golden_dir, name, over):
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
+    cfg = R.make_cfg(**over)
+    sd = R.synth_state_dict(R.param_shapes(cfg), int(g["wseed"]), bool(int(g["trained_like"])))
+    lens = [int(v) for v in g["lens"]]
+    x = synth_inputs(cfg, lens, int(g["xseed"]))
+    for b, n in enumerate(lens):
+        o = R.infer_clip(sd, cfg, x[b, :, :n], dict(fps=25.0, duration=n / 25.0, feat_stride=1.0, feat_num_frames=1.0))
+        assert float((o["logits"][:, 0] - torch.from_numpy(g["logits"][b, :, 0])).abs().max()) < 2e-5
+        assert float((o["offsets"] - torch.from_numpy(g["offsets"][b])).abs().max()) < 2e-4
+        k = int(g["n_segments"][b])
+        assert o["segments"].shape[0] == k
+        ref_pts = g["kept_points"][b][:k]
+        assert sorted(o["kept_points"].tolist()) == sorted(ref_pts.tolist()), f"{name} clip {b}: kept point sets differ"
+        order = {int(p): i for i, p in enumerate(o["kept_points"].tolist())}
+        perm = torch.tensor([order[int(p)] for p in ref_pts], dtype=torch.int64)
+        if k:
+            assert float((o["segments"][perm] - torch.from_numpy(g["segments"][b][:k])).abs().max()) < 1e-4
+            assert float((o["scores"][perm] - torch.from_numpy(g["scores"][b][:k])).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID),
+                                       ("train_the_small", dict(variant="the", **SMALL)),
+                                       ("train_recon_small", dict(variant="recon", **SMALL))])
+def test_oracle_training_losses_and_gradients_match_reference(golden_dir, name, over):
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
+    cfg = R.make_cfg(**over)
+    sd = R.synth_state_dict(R.param_shapes(cfg), int(g["wseed"]), True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lens = [int(v) for v in g["lens"]]
+    x = synth_inputs(cfg, lens, int(g["xseed"]))
+    mask = (torch.arange(cfg["max_seq_len"])[None, :] < torch.tensor(lens)[:, None]).float()[:, None, :]
+    gts = [torch.from_numpy(np.asarray(s, np.float32)) if f else None for s, f in zip(g["gt_segments"], g["is_fake"])]
+    gls = [None if s is None else torch.zeros(len(s), dtype=torch.int64) for s in gts]
+    the = cfg["variant"] == "the"
+    gfl = [None if (s is None) else torch.from_numpy(np.asarray(f, np.float32)) for s, f in zip(gts, g["gt_frame_labels"])]
+    out = R.model_forward(sd, cfg, x, mask, training=True)
+    ol, norm, _ = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], x_in=x, gt_frame_labels=gfl if the else None)
+    ol["final_loss"].backward()
+    got = np.array([float(ol[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
+    assert np.allclose(got, g["losses"], rtol=1e-4, atol=1e-6), (got, g["losses"])
+    assert abs(norm - float(g["loss_normalizer"])) < 1e-4
+    for key in g.files:
+        if not key.startswith("grad::"):
+            continue
+        flat = sd[key[6:]].grad.flatten()
+        stride = max(1, flat.numel() // 4096)
+        ref = torch.from_numpy(g[key])
+        rel = float((flat[::stride][:4096] - ref).abs().max() / (ref.abs().max() + 1e-12))
+        assert rel < 2e-3, (key, rel)
+
+
+def test_oracle_interp_matches_reference_bit_exact(golden_dir):
+    """K1: F.interpolate x3 + cat of the reference's dataset (deepfake_video_audio.py:1722-1756) incl. its in-source known answer."""
+    g = np.load(os.path.join(golden_dir, "interp.npz"), allow_pickle=True)
+    for i in range(int(g["n_cases"])):
+        out = R.interp_concat([g[f"v{i}"], g[f"a{i}"], g[f"e{i}"]], int(g[f"out{i}"].shape[-1]))
+        assert np.array_equal(out.numpy(), g[f"out{i}"]), f"interp case {i}"
+    kin = torch.from_numpy(np.asarray(g["known_in"], np.float32)).reshape(1, 1, -1)
+    kout = torch.nn.functional.interpolate(kin, size=int(np.asarray(g["known_out"]).size), mode="linear", align_corners=False)
+    assert np.allclose(kout.numpy().ravel(), np.asarray(g["known_out"]).ravel())
+
+
+def test_oracle_nms_matches_reference_native_op(golden_dir):
+    """nms_1d_numpy against the reference's compiled nms_1d_cpu (nms_cpu.cpp:19-58) keep lists (incl. ties, n = 0 / 1)."""
+    g = np.load(os.path.join(golden_dir, "nms.npz"))
+    for i in range(int(g["n_cases"])):
+        segs = np.asarray(g[f"segs{i}"], np.float32).reshape(-1, 2)
+        sc = np.asarray(g[f"scores{i}"], np.float32)
+        keep = np.asarray(R.nms_1d_numpy(segs, sc, 0.1), dtype=np.int64)
+        ref = g[f"keep{i}"]
+        assert sorted(keep.tolist()) == sorted(ref.tolist()), f"nms case {i}"
+        assert np.array_equal(sc[keep], sc[ref]), f"nms case {i}: score order"
