@@ -154,7 +154,7 @@ __device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3 = false>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3 = false, bool DB = false>
 __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
     FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy,
     long xbs, long wbs, long ybs) {
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   constexpr int LDAH = KC + 8, LDBH = KB + 8;
   constexpr int ASH = RA * LDAH, BSH = BN * LDBH;
   static_assert(!BF3 || KCG % 16 == 0, "bf16x3 needs 16-deep k-steps per K-group");
-  constexpr int SM = cmax(BF3 ? (ASH + BSH) : (AS + BSZ), KG * BM * (BN + 4));
+  // DB: two operand buffers -- the next stage is stored while other waves still compute from the current one, one
+  // barrier per K-stage instead of two (long-K problems; costs co-residency, so the plan decides)
+  constexpr int TILE = round4(BF3 ? (ASH + BSH) : (AS + BSZ));
+  constexpr int SM = cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
   float* Bs = smem + AS;
@@ -235,7 +238,13 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       rb.v[i] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int boff) {
+    float* As = smem + boff;
+    float* Bs = As + AS;
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem + boff);
+    __bf16* Al = Ah + ASH;
+    __bf16* Bh = Al + ASH;
+    __bf16* Bl = Bh + BSH;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int row, c4;
@@ -284,11 +293,18 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   const int nk = (Cin + KC - 1) / KC;
   AVDF_PROBE(0);
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
   AVDF_PROBE(1);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
+    const int coff = (DB && (kt & 1)) ? TILE : 0;
+    float* As = smem + coff;
+    float* Bs = As + AS;
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem + coff);
+    __bf16* Al = Ah + ASH;
+    __bf16* Bh = Al + ASH;
+    __bf16* Bl = Bh + BSH;
     if constexpr (BF3) {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
@@ -341,13 +357,18 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
       }
     }
     }
-    __syncthreads();
-    AVDF_PROBE(2 + 2 * kt);
-    if (kt + 1 < nk) {
-      store_tile();
+    if constexpr (DB) {
+      if (kt + 1 < nk) store_tile((kt & 1) ? 0 : TILE);
       __syncthreads();
+    } else {
+      __syncthreads();
+      AVDF_PROBE(2 + 2 * kt);
+      if (kt + 1 < nk) {
+        store_tile(0);
+        __syncthreads();
+      }
+      AVDF_PROBE(3 + 2 * kt);
     }
-    AVDF_PROBE(3 + 2 * kt);
   }
   AVDF_PROBE(14);
   const bool vec = ((ldy & 3) == 0) && ((ybs & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 // data gradient
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false>
 __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
     DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
   const int prob = blockIdx.z;
@@ -399,7 +420,8 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   constexpr int A4 = KC / 4, B4 = LDB / 4;
   constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (KC * B4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = KC * LDB;
-  constexpr int SM = cmax(AS + BSZ, KG * BM * (BN + 4));
+  constexpr int TILE = round4(AS + BSZ);
+  constexpr int SM = cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
   constexpr int KCG = KC / KG;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
@@ -460,7 +482,9 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
       rb.v[i] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int boff) {
+    float* As = smem + boff;
+    float* Bs = As + AS;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int rr, c4;
@@ -479,12 +503,13 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
 
   const int nk = (Cout + KC - 1) / KC;
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
-    const float* Ag = As + kg * KCG;
-    const float* Bg = Bs + kg * KCG * LDB;
+    const int coff = (DB && (kt & 1)) ? TILE : 0;
+    const float* Ag = smem + coff + kg * KCG;
+    const float* Bg = smem + coff + AS + kg * KCG * LDB;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
 #pragma unroll
@@ -505,10 +530,15 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
             acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
       }
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
+    if constexpr (DB) {
+      if (kt + 1 < nk) store_tile((kt & 1) ? 0 : TILE);
       __syncthreads();
+    } else {
+      __syncthreads();
+      if (kt + 1 < nk) {
+        store_tile(0);
+        __syncthreads();
+      }
     }
   }
   const bool vec = ((Cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
@@ -750,7 +780,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // >= 2 workgroups per CU wins, otherwise the shape with the most workgroups; then as many K-groups
 // as needed to put ~1024+ wave-quads on the chip.
 // tile 0: 128x128  1: 64x128  2: 64x64  3: 32x128
-struct TilePlan { int tile, kg; };
+struct TilePlan { int tile, kg, db; };
 
 // ---- measured plans ----------------------------------------------------------------------------------------
 // tools/autotune.py times every (tile, K-groups) / (token-splits, K-groups) choice for the GEMM shapes of a training
@@ -775,7 +805,7 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
     const int kind = dgrad ? 1 : 0;
     const int mk_[5] = {1, 2, 4, 4, 2};
     if (g_override[kind][0] >= 0) {
-      TilePlan o{g_override[kind][0], g_override[kind][1]};
+      TilePlan o{g_override[kind][0], g_override[kind][1] & 7, (g_override[kind][1] >> 3) & 1};
       if (o.tile > 4) o.tile = 4;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
@@ -783,11 +813,11 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
     }
     if (K > 0 && g_override[kind][0] != -2) {          // -2: heuristic only (the tuner's baseline)
       const TunedPlan* t = tuned_lookup(kind, K, stride, B * T, N, Kred);
-      if (t) return TilePlan{t->a, t->b};
+      if (t) return TilePlan{t->a, t->b & 7, (t->b >> 3) & 1};
     }
   }
   const int bm[4] = {128, 64, 64, 32}, bn[4] = {128, 128, 64, 128};
-  TilePlan p{0, 1};
+  TilePlan p{0, 1, 0};
   long best_blocks = -1;
   for (int c = 0; c < 4; ++c) {
     const long blocks = (long)B * cdiv(T, bm[c]) * cdiv(N, bn[c]);
@@ -899,9 +929,19 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
     const int tilesT = cdiv(Tout, BM_);                                                                 \
     dim3 grid(B * tilesT, cdiv(Cout, BN_), nprob);                                                      \
+    constexpr int RA_ = (BM_ - 1) * S_ + KS_;                                                           \
+    constexpr bool DBOK_ = 2 * (RA_ * (KC_ + 1) + BN_ * (KC_ * KS_ + 1) + 8) * 4 <= 150 * 1024;         \
     if constexpr ((KC_ / KG_) % 16 == 0) {                                                              \
       if (g_gemm_mode == 1) {                                                                           \
         hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
+                           dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
+                           ldx, ldw, ldy, xbs, wbs, ybs);                                               \
+        break;                                                                                          \
+      }                                                                                                 \
+    }                                                                                                   \
+    if constexpr (DBOK_) {                                                                              \
+      if (plan.db) {                                                                                    \
+        hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, false, true>), grid, \
                            dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
                            ldx, ldw, ldy, xbs, wbs, ybs);                                               \
         break;                                                                                          \
@@ -987,6 +1027,15 @@ static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin,
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                             \
     const int tilesT = cdiv(Tin, BM_);                                                                    \
     dim3 grid(B * tilesT, cdiv(Cin, BN_), nprob);                                                         \
+    constexpr int RAd_ = (BM_ + KS_ - 2) / S_ + 2;                                                        \
+    constexpr bool DBOK_ = 2 * (RAd_ * (KC_ + 1) + KC_ * BN_ * KS_ + 8) * 4 <= 150 * 1024;                \
+    if constexpr (DBOK_) {                                                                                \
+      if (plan.db) {                                                                                      \
+        hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
+                           dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);           \
+        break;                                                                                            \
+      }                                                                                                   \
+    }                                                                                                     \
     hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);                                \
   } while (0)

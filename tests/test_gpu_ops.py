@@ -493,3 +493,38 @@ def test_conv1d_forward_bf16x3_mode(ops, case):
     close(y1, ref, "bf16x3 conv fwd", rtol=2e-5)
     close(y0, ref, "fp32 conv fwd", rtol=2e-6 if Cin * K < 4096 else 5e-6)
     # (plans whose K-group slice is not a multiple of 16 keep the exact kernel even in mode 1, so y0 may equal y1)
+
+
+@pytest.mark.parametrize("shape", [(2, 200, 96, 136, 3, 1), (3, 192, 256, 64, 1, 1), (2, 96, 64, 40, 3, 2), (1, 520, 1024, 256, 1, 1)])
+def test_conv1d_every_gemm_plan(ops, shape):
+    """Every (tile, K-groups, double-buffer) plan the tuner may select, forced through avdf_gemm_override, for the
+    forward and the data-gradient kernels, against float64."""
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    B, T, Cin, Cout, K, s = shape
+    Tout = (T + 2 * (K // 2) - K) // s + 1
+    x, w = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, K, seed=2, scale=(Cin * K) ** -0.5)
+    dy = rnd(B, Tout, Cout, seed=3)
+    x64, w64 = x.clone().requires_grad_(True), w.clone()
+    ref = F.conv1d(x64.transpose(1, 2), w64, None, s, K // 2).transpose(1, 2)
+    (ref * dy).sum().backward()
+    xd, wd, dyd = g32(x), g32(w), g32(dy)
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        for tile in range(5):
+            for kg in (1, 2, 4):
+                if kg > (1, 2, 4, 4, 2)[tile]:
+                    continue
+                for db in (0, 1):
+                    check(lib.avdf_gemm_override(0, tile, kg + 8 * db), "override")
+                    check(lib.avdf_gemm_override(1, tile, kg + 8 * db), "override")
+                    y = torch.empty(B, Tout, Cout, device=dev())
+                    dx = torch.empty(B, T, Cin, device=dev())
+                    check(lib.avdf_conv1d_fwd(xd.data_ptr(), wd.data_ptr(), None, None, y.data_ptr(), None, B, T, Cin, Tout, Cout,
+                                              K, s, 0, st), "fwd")
+                    check(lib.avdf_conv1d_bwd_data(dyd.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T, Cin, Tout, Cout,
+                                                   K, s, 0, st), "dgrad")
+                    close(y, ref, f"fwd tile {tile} kg {kg} db {db}")
+                    close(dx, x64.grad, f"dgrad tile {tile} kg {kg} db {db}")
+    finally:
+        for k in range(3):
+            check(lib.avdf_gemm_override(k, -1, -1), "override")

@@ -49,10 +49,10 @@ def bench_shape(shape, iters):
     T = lambda ts: ops._ptr_table(ts)
     if kind == "fwd":
         fn = lambda: check(lib.avdf_conv1d_fwd_grouped(n, T(xs), T(ws_), None, None, T(ys), None, B, Tin, Cin, Tout, Cout, K, s, 0, st()), "f")
-        cands = [(t, kg) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t]]
+        cands = [(t, kg + 8 * db) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t] for db in (0, 1)]
     elif kind == "dgrad":
         fn = lambda: check(lib.avdf_conv1d_bwd_data_grouped(n, T(ys), T(ws_), None, None, T(xs), B, Tin, Cin, Tout, Cout, K, s, 0, st()), "d")
-        cands = [(t, kg) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t]]
+        cands = [(t, kg + 8 * db) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t] for db in (0, 1)]
     else:
         wsb = torch.empty(8, device=dev)
         fn = lambda: check(lib.avdf_conv1d_bwd_weight_grouped(n, T(ys), T(xs), None, None, T(dws), None, wsb.data_ptr(), B, Tin, Cin, Tout,
