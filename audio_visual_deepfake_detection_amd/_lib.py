@@ -78,6 +78,7 @@ SIGNATURES = {
     "avdf_conv2d_c1_bn_relu_pool": (I, [P, P, P, P, P, I, I, I, P]),
     "avdf_mel_im2col": (I, [P, P, I, I, I, P]),
     "avdf_maxpool2x2": (I, [P, P, I, I, I, I, P]),
+    "avdf_softnms1d_host": (I, [P, P, L, F, F, F, I, P, P, P]),
     "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
     "avdf_wave_conv_c1": (I, [P, P, P, L, L, I, I, I, P]),
     "avdf_grouped_conv_pos": (I, [P, P, P, P, I, I, I, I, P]),

@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 #include "../../include/avdf.h"
 
@@ -92,5 +93,50 @@ extern "C" int avdf_batched_nms_host(const float* segs, const float* scores, int
     out_segs[2 * q] = a0; out_segs[2 * q + 1] = a1; out_scores[q] = scores[i]; out_idx[q] = i;
   }
   *n_out = nk;      // NMS order is already descending-score: the final sort of nms.py:182-189 is the identity
+  return AVDF_OK;
+}
+
+// Soft-NMS (Bodla et al. 2017) with the reference's conventions (softnms_1d_cpu, libs/utils/csrc/nms_cpu.cpp:67-158):
+// repeatedly take the live segment with the highest CURRENT score (first one in array order on ties), emit it, decay
+// the scores of the remaining live ones by their IoU with it (method 0: hard, 1: linear above iou_thr, 2: gaussian
+// exp(-iou^2/sigma)) and drop a segment as soon as its score falls below min_score.  The working set is kept as a
+// compact array: position i is swapped with the maximum, a dropped entry is overwritten by the last live one (that
+// order decides exact ties, so it is part of the contract).  dets [n,3] = (x1, x2, decayed score) in emission
+// order, inds = their indices into the input; both hold *n_out valid rows.  HOST pointers.
+extern "C" int avdf_softnms1d_host(const float* segs, const float* scores, int64_t n, float iou_thr, float sigma,
+                                   float min_score, int method, float* dets, int64_t* inds, int64_t* n_out) {
+  if (n < 0 || !n_out || method < 0 || method > 2 || (n > 0 && (!segs || !scores || !dets || !inds))) {
+    avdf_set_error("softnms1d_host: bad args");
+    return AVDF_EINVAL;
+  }
+  struct Live { float a, b, score, len; int64_t src; };
+  std::vector<Live> live((size_t)n);
+  for (int64_t i = 0; i < n; ++i) live[(size_t)i] = Live{segs[2 * i], segs[2 * i + 1], scores[i], segs[2 * i + 1] - segs[2 * i] + 1e-6f, i};
+  int64_t m = n;                                   // live count; [0, i) already emitted
+  for (int64_t i = 0; i < m; ++i) {
+    int64_t top = i;
+    for (int64_t p = i + 1; p < m; ++p)
+      if (live[(size_t)top].score < live[(size_t)p].score) top = p;
+    std::swap(live[(size_t)i], live[(size_t)top]);
+    const Live cur = live[(size_t)i];
+    dets[3 * i] = cur.a; dets[3 * i + 1] = cur.b; dets[3 * i + 2] = cur.score;
+    for (int64_t p = i + 1; p < m; ++p) {
+      Live& o = live[(size_t)p];
+      const float inter = std::max(0.f, std::min(cur.b, o.b) - std::max(cur.a, o.a));
+      const float ovr = inter / (cur.len + o.len - inter);
+      float wgt = 1.f;
+      if (method == 0) { if (ovr >= iou_thr) wgt = 0.f; }
+      else if (method == 1) { if (ovr >= iou_thr) wgt = 1.f - ovr; }
+      else wgt = std::exp(-(ovr * ovr) / sigma);
+      o.score *= wgt;
+      if (o.score < min_score) {
+        o = live[(size_t)(m - 1)];
+        --m;
+        --p;                                       // re-examine the entry moved into this slot
+      }
+    }
+  }
+  for (int64_t i = 0; i < m; ++i) inds[i] = live[(size_t)i].src;
+  *n_out = m;
   return AVDF_OK;
 }

@@ -262,6 +262,10 @@ int avdf_conv2d_c1_bn_relu_pool(const float* x /*[M,T]*/, const float* w /*[C,9]
 int avdf_mel_im2col(const float* x /*[M,T,C]*/, float* xcol /*[M,T,3C]*/, int M, int T, int C, void* stream);
 int avdf_maxpool2x2(const float* x /*[M,T,C]*/, float* out, int M, int T, int C, int t_major, void* stream);
 
+/* Soft-NMS of the reference's native module (`nms_1d_cpu.softnms`, libs/utils/csrc/nms_cpu.cpp:67-158; method 0 hard,
+ * 1 linear, 2 gaussian).  dets [n,3] = (x1, x2, decayed score) in emission order, inds = source indices.  HOST pointers. */
+int avdf_softnms1d_host(const float* segs, const float* scores, int64_t n, float iou_thr, float sigma,
+                        float min_score, int method, float* dets, int64_t* inds, int64_t* n_out);
 /* host mirror of batched_nms (class-agnostic hard branch) + seg_voting (libs/utils/nms.py:67-190); HOST pointers */
 int avdf_batched_nms_host(const float* segs, const float* scores, int64_t n, float iou_thr, float min_score,
                           int64_t max_seg, float voting_thr, float* out_segs, float* out_scores,

@@ -273,6 +273,30 @@ def case_nms():
     print("[nms] stored", cases["n_cases"], "cases")
 
 
+def case_nms_modes():
+    """The reference's batched_nms (libs/utils/nms.py:103-190, native nms_1d_cpu incl. softnms) in its soft /
+    multiclass branches, on several classes with duplicated scores."""
+    from libs.utils.nms import batched_nms
+    out = {}
+    rs = np.random.RandomState(77)
+    ci = 0
+    for n in (0, 1, 7, 60, 300):
+        st = rs.uniform(0, 100, n).astype(np.float32)
+        segs = np.stack([st, st + rs.uniform(0.5, 20, n).astype(np.float32)], 1).reshape(-1, 2)
+        sc = np.round(rs.uniform(0, 1, n), 2).astype(np.float32)
+        cls = rs.randint(0, 3, n).astype(np.int64)
+        for soft, multi in ((True, True), (True, False), (False, True)):
+            s, c, l = batched_nms(torch.from_numpy(segs), torch.from_numpy(sc), torch.from_numpy(cls), 0.1, 0.001, 100,
+                                  use_soft_nms=soft, multiclass=multi, sigma=0.5, voting_thresh=0.75)
+            out[f"c{ci}_in"] = np.concatenate([segs, sc[:, None], cls[:, None].astype(np.float32)], 1)
+            out[f"c{ci}_mode"] = np.array([int(soft), int(multi)])
+            out[f"c{ci}_segs"], out[f"c{ci}_scores"], out[f"c{ci}_cls"] = s.numpy(), c.numpy(), l.numpy()
+            ci += 1
+    out["n_cases"] = np.array(ci)
+    np.savez_compressed(os.path.join(GOLD, "nms_modes.npz"), **out)
+    print("[nms_modes] stored", ci, "cases")
+
+
 def case_interp():
     import torch.nn.functional as F
     out = {}
@@ -436,6 +460,7 @@ def main():
     ctx = import_reference()
     case_interp()
     case_nms()
+    case_nms_modes()
     case_datasets()
     case_metrics()
     case_lr_schedules()
@@ -462,6 +487,10 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, import_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "nms_modes":
+        os.makedirs(GOLD, exist_ok=True)
+        import_reference()
+        case_nms_modes()
     elif len(sys.argv) > 1 and sys.argv[1] == "lr":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()

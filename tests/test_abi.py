@@ -92,3 +92,27 @@ def test_batched_nms_api_matches_reference_outputs(golden_dir):
             o1 = np.lexsort((s.numpy()[:, 0], -c.numpy()))
             o2 = np.lexsort((rs[:, 0], -rc))
             assert np.allclose(s.numpy()[o1], rs[o2], atol=1e-3), (i, tag)
+
+
+def test_batched_nms_soft_and_multiclass_branches_match_reference(golden_dir):
+    """(soft | hard) x (multiclass | agnostic) branches of libs.utils.batched_nms vs the reference's outputs
+    (tests/golden/nms_modes.npz: its compiled nms_1d_cpu.nms / .softnms + seg_voting), incl. n = 0 / 1 and score ties."""
+    import numpy as np
+    import torch
+    from audio_visual_deepfake_detection_amd.libs.utils import batched_nms
+    g = np.load(os.path.join(golden_dir, "nms_modes.npz"))
+    for i in range(int(g["n_cases"])):
+        a = g[f"c{i}_in"].reshape(-1, 4)
+        soft, multi = (bool(v) for v in g[f"c{i}_mode"])
+        s, c, l = batched_nms(torch.from_numpy(a[:, :2].copy()), torch.from_numpy(a[:, 2].copy()),
+                              torch.from_numpy(a[:, 3].astype(np.int64)), 0.1, 0.001, 100, use_soft_nms=soft, multiclass=multi,
+                              sigma=0.5, voting_thresh=0.75)
+        rs, rc, rl = g[f"c{i}_segs"], g[f"c{i}_scores"], g[f"c{i}_cls"]
+        assert s.shape[0] == rs.shape[0], (i, soft, multi, s.shape, rs.shape)
+        if rs.shape[0] == 0:
+            continue
+        assert np.allclose(np.sort(c.numpy())[::-1], np.sort(rc)[::-1], atol=1e-6), (i, soft, multi)
+        o1 = np.lexsort((s.numpy()[:, 0], l.numpy(), -np.round(c.numpy(), 5)))
+        o2 = np.lexsort((rs[:, 0], rl, -np.round(rc, 5)))
+        assert np.allclose(s.numpy()[o1], rs[o2], atol=1e-3), (i, soft, multi)
+        assert np.array_equal(l.numpy()[o1], rl[o2]), (i, soft, multi)
