@@ -14,11 +14,13 @@ from . import libs          # noqa: F401
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
 
-def build_model(yaml_name="deepfake_exp10.yaml", **model_overrides):
-    """Convenience: meta-arch from a packaged YAML with optional cfg['model'] overrides."""
+def build_model(yaml_name="deepfake_exp10.yaml", model_name=None, **model_overrides):
+    """Convenience: meta-arch from a packaged YAML with optional cfg['model'] overrides (and meta-arch name)."""
     from .libs.core import load_config
     from .libs.modeling import make_meta_arch
     cfg = load_config(os.path.join(CONFIG_DIR, yaml_name))
+    if model_name is not None:
+        cfg["model_name"] = model_name
     ds_keys = ("video_input_dim", "audio_input_dim", "max_seq_len", "num_classes")
     for k, v in model_overrides.items():
         cfg["model"][k] = v

@@ -98,3 +98,58 @@ class ConvHRLRFullResSelfAttTransformerBackboneRevised(nn.Module):
                 x, mask = self.hh_branch[idx](x, mask, x_k=dn, mask_k=mask, x_v=dn, mask_v=mask)
         out_feats[0], out_masks[0] = lh_feat, lh_mask
         return out_feats, out_masks
+
+
+@register_backbone("convTransformer")
+class ConvTransformerBackbone(nn.Module):
+    """ActionFormer backbone (reference: libs/modeling/backbones.py:10-168): conv embedding (+LN, ReLU, abs PE) ->
+    stem TransformerBlocks -> branch TransformerBlocks with stride-`scale_factor` pooling; every branch output is a
+    pyramid level.  forward(x [B,T,C] time-major, mask [B,T]) -> (feats, masks) tuples of arch[2]+1 levels."""
+
+    def __init__(self, n_in, n_embd, n_head, n_embd_ks, max_len, arch=(2, 2, 5), mha_win_size=[-1] * 6,
+                 scale_factor=2, with_ln=False, attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, use_abs_pe=False,
+                 use_rel_pe=False, use_time_weight=False):
+        super().__init__()
+        assert len(arch) == 3 and len(mha_win_size) == (1 + arch[2])
+        assert not isinstance(n_in, (list, tuple)), "per-stream projection is unused by the shipped configs"
+        assert with_ln, "embd_with_ln is True in every shipped config (libs/core/config.py:63)"
+        self.n_in, self.arch, self.mha_win_size, self.max_len = n_in, arch, mha_win_size, max_len
+        self.scale_factor, self.use_abs_pe = scale_factor, use_abs_pe
+        self.proj = None
+        self.embd = nn.ModuleList()
+        self.embd_norm = nn.ModuleList()
+        for idx in range(arch[0]):
+            self.embd.append(MaskedConv1D(n_in if idx == 0 else n_embd, n_embd, n_embd_ks, stride=1,
+                                          padding=n_embd_ks // 2, bias=(not with_ln)))
+            self.embd_norm.append(LayerNorm(n_embd))
+        if use_abs_pe:
+            pos_embd = get_sinusoid_encoding(max_len, n_embd) / (n_embd ** 0.5)
+            self.register_buffer("pos_embd", pos_embd, persistent=False)
+            self.register_buffer("pos_embd_tm", pos_embd[0].t().contiguous(), persistent=False)
+        blk = dict(attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop, path_pdrop=path_pdrop, use_rel_pe=use_rel_pe,
+                   use_time_weight=use_time_weight)
+        self.stem = nn.ModuleList([TransformerBlock(n_embd, n_head, n_ds_strides=(1, 1), mha_win_size=mha_win_size[0],
+                                                    **blk) for _ in range(arch[1])])
+        self.branch = nn.ModuleList([TransformerBlock(n_embd, n_head, n_ds_strides=(scale_factor, scale_factor),
+                                                      mha_win_size=mha_win_size[1 + idx], **blk)
+                                     for idx in range(arch[2])])
+        self.apply(self.__init_weights__)
+
+    def __init_weights__(self, module):
+        if isinstance(module, (nn.Linear, nn.Conv1d)) and module.bias is not None:
+            torch.nn.init.constant_(module.bias, 0.)
+
+    _embed = ConvHRLRFullResSelfAttTransformerBackboneRevised._embed
+
+    def forward(self, x, mask):
+        if self.training:
+            plan_drop_path(self, x.shape[0], x.device)
+        x = self._embed(x, mask)
+        for blk in self.stem:
+            x, mask = blk(x, mask)
+        out_feats, out_masks = [x], [mask]
+        for blk in self.branch:
+            x, mask = blk(x, mask)
+            out_feats.append(x)
+            out_masks.append(mask)
+        return out_feats, out_masks

@@ -129,6 +129,8 @@ class PtTransformerRegHead(nn.Module):
 class AVPtTransformerRecovery(nn.Module):
     """exp10 / exp12 model (configs_train/deepfake_exp10.yaml, configs_test/deepfake_exp12_test.yaml)."""
 
+    BACKBONES = ('convHRLRFullResSelfAttTransformerRevised',)
+
     def __init__(self, backbone_type, fpn_type, backbone_arch, scale_factor, video_input_dim, audio_input_dim,
                  max_seq_len, max_buffer_len_factor, n_head, n_mha_win_size, embd_kernel_size, embd_dim, embd_with_ln,
                  fpn_dim, fpn_with_ln, fpn_start_level, head_dim, regression_range, head_num_layers,
@@ -179,7 +181,7 @@ class AVPtTransformerRecovery(nn.Module):
         self.test_nms_sigma = test_cfg['nms_sigma']
         self.test_voting_thresh = test_cfg['voting_thresh']
 
-        assert backbone_type in ['convHRLRFullResSelfAttTransformerRevised']
+        assert backbone_type in self.BACKBONES, (backbone_type, self.BACKBONES)
         self.backbone = make_backbone(backbone_type, **{
             'n_in': input_dim, 'n_embd': embd_dim, 'n_head': n_head, 'n_embd_ks': embd_kernel_size,
             'max_len': max_seq_len, 'arch': backbone_arch, 'mha_win_size': self.mha_win_size,
@@ -286,7 +288,7 @@ class AVPtTransformerRecovery(nn.Module):
         video logits [B,1], per-level lengths)."""
         self._front_input = x
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
-        feats, masks = self.backbone(x, reco_x, mask)
+        feats, masks = self._run_backbone(x, reco_x, mask)
         fpn_feats, fpn_masks = self.neck(feats, masks)
         lens = [int(f.shape[1]) for f in fpn_feats]
         gx, gmask, gidx, keep = gap_levels(fpn_feats, fpn_masks)
@@ -294,6 +296,9 @@ class AVPtTransformerRecovery(nn.Module):
         offsets = self.reg_head.forward_gapped(gx, gmask, keep, lens).index_select(1, gidx)
         pmask = torch.cat(fpn_masks, dim=1)
         return logits, offsets, pmask, cls_scores, lens
+
+    def _run_backbone(self, x, reco_x, mask):
+        return self.backbone(x, reco_x, mask)
 
     def forward(self, video_list):
         if not self.training:
@@ -417,3 +422,49 @@ class AVPtTransformerRecoveryNoNorm(AVPtTransformerRecovery):
         losses['reco_loss'] = reco_loss.detach()
         losses['final_loss'] = losses['final_loss'] + reco_loss
         return losses
+
+
+@register_meta_arch("LocPointTransformer")
+class PtTransformer(AVPtTransformerRecovery):
+    """Plain single-stage localiser (reference: libs/modeling/meta_archs.py:162-700; the `model_name` default of
+    libs/core/config.py): convTransformer backbone -> FPN -> heads, no video-level branch.  Training expects every clip
+    to carry segments (meta_archs.py:346-348); losses / results have the reference's keys (no `reco_cls_loss`, no
+    `video_cls`)."""
+
+    BACKBONES = ('convTransformer',)
+
+    def __init__(self, backbone_type, fpn_type, backbone_arch, scale_factor, max_seq_len, max_buffer_len_factor, n_head,
+                 n_mha_win_size, embd_kernel_size, embd_dim, embd_with_ln, fpn_dim, fpn_with_ln, fpn_start_level, head_dim,
+                 regression_range, head_num_layers, head_kernel_size, head_with_ln, use_abs_pe, use_rel_pe, num_classes,
+                 train_cfg, test_cfg, input_dim=None, audio_input_dim=0, video_input_dim=None):
+        # the reference's signature takes `input_dim` (meta_archs.py:172-173) while its config loader fills
+        # `video_input_dim` / `audio_input_dim` (libs/core/config.py:151-152): both spellings are accepted here
+        if input_dim is None:
+            input_dim = int(video_input_dim) + int(audio_input_dim or 0)
+        super().__init__(backbone_type, fpn_type, backbone_arch, scale_factor, input_dim, 0, max_seq_len,
+                         max_buffer_len_factor, n_head, n_mha_win_size, embd_kernel_size, embd_dim, embd_with_ln, fpn_dim,
+                         fpn_with_ln, fpn_start_level, head_dim, regression_range, head_num_layers, head_kernel_size,
+                         head_with_ln, use_abs_pe, use_rel_pe, num_classes, train_cfg, test_cfg)
+        self.video_loss_weight = 0.0
+
+    def _build_front(self, input_dim, embd_dim):
+        pass
+
+    def _front(self, x, mask):
+        return torch.zeros((x.shape[0], 1), dtype=torch.float32, device=x.device), None, None
+
+    def _run_backbone(self, x, reco_x, mask):
+        return self.backbone(x, mask)
+
+    def _pack_gt(self, video_list, dev):
+        assert all(v.get('segments') is not None for v in video_list), "GT action labels does not exist"
+        return super()._pack_gt(video_list, dev)
+
+    def _extra_losses(self, losses, video_list):
+        return {k: losses[k] for k in ('cls_loss', 'reg_loss', 'final_loss')}
+
+    def inference(self, video_list, points, pmask, logits, offsets, cls_scores, lens):
+        results = super().inference(video_list, points, pmask, logits, offsets, cls_scores, lens)
+        for r in results:
+            r.pop('video_cls')
+        return results

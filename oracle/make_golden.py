@@ -37,7 +37,23 @@ def import_reference():
     return load_config, C, make_meta_arch
 
 
+def ref_model_plain(load_config, C, make_meta_arch, cfg):
+    """The reference's LocPointTransformer (meta_archs.py:162) with exp10's hyper-parameters; its constructor takes
+    `input_dim`, which the reference's own config loader never fills, so the kwargs are assembled here."""
+    import importlib
+    importlib.import_module("libs.modeling.meta_archs")      # not imported by libs/modeling/__init__.py: registers it
+    rc = load_config(f"{REF}/configs_train/deepfake_exp10.yaml", defaults=copy.deepcopy(C.DEFAULTS))
+    m = dict(rc["model"])
+    m.pop("video_input_dim")
+    m.pop("mlp_ratio", None)
+    m.update(backbone_type="convTransformer", input_dim=cfg["input_dim"], audio_input_dim=0, max_seq_len=cfg["max_seq_len"],
+             embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"], head_dim=cfg["head_dim"], n_head=cfg["n_head"])
+    return make_meta_arch("LocPointTransformer", **m), rc
+
+
 def ref_model(load_config, C, make_meta_arch, yaml_name, cfg):
+    if cfg["variant"] == "plain":
+        return ref_model_plain(load_config, C, make_meta_arch, cfg)
     rc = load_config(f"{REF}/configs_train/{yaml_name}", defaults=copy.deepcopy(C.DEFAULTS))
     m = rc["model"]
     vdim = max(8, cfg["input_dim"] // 12)
@@ -61,6 +77,13 @@ def synth_inputs(cfg, lens, seed):
 def ref_forward_heads(model, x, mask_f):
     """Replays av_fd_no_recon.py:346-379 on pre-batched tensors (so B>1 works in eval)."""
     mb = mask_f > 0
+    if type(model).__name__ == "PtTransformer" and type(model).__module__.endswith("meta_archs"):
+        feats, masks = model.backbone(x, mb)                              # meta_archs.py:335-345
+        fpn_feats, fpn_masks = model.neck(feats, masks)
+        logits = [t.permute(0, 2, 1) for t in model.cls_head(fpn_feats, fpn_masks)]
+        offsets = [t.permute(0, 2, 1) for t in model.reg_head(fpn_feats, fpn_masks)]
+        return dict(logits=logits, offsets=offsets, cls_scores=torch.zeros(x.shape[0], 1), feats=feats, fpn=fpn_feats,
+                    masks=[m.squeeze(1) for m in fpn_masks])
     front = model.interpolator if hasattr(model, "interpolator") else model.segmentandCls
     norm_inputs, reco, cls_scores = front(x, mb)
     recon = type(model).__module__.endswith("av_fd_meta_arch")        # exp5: Expansion output feeds the backbone
@@ -89,7 +112,8 @@ def match_segments(seg_a, sc_a, seg_b, sc_b):
 
 
 def yaml_for(cfg):
-    return {"norecon": "deepfake_exp10.yaml", "the": "deepfake_exp13.yaml", "recon": "deepfake_exp5.yaml"}[cfg["variant"]]
+    return {"norecon": "deepfake_exp10.yaml", "the": "deepfake_exp13.yaml", "recon": "deepfake_exp5.yaml",
+            "plain": "deepfake_exp10.yaml"}[cfg["variant"]]
 
 
 def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_levels=True):
@@ -109,7 +133,7 @@ def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_le
         mine = R.model_forward(sd, cfg, x, mask)
     dl = max(maxdiff(a, b) for a, b in zip(ref["logits"], mine["logits"]))
     do = max(maxdiff(a, b) for a, b in zip(ref["offsets"], mine["offsets"]))
-    dc = maxdiff(ref["cls_scores"], mine["cls_scores"])
+    dc = 0.0 if mine["cls_scores"] is None else maxdiff(ref["cls_scores"], mine["cls_scores"])
     df = max(maxdiff(a, b) for a, b in zip(ref["fpn"], mine["fpn"]))
     print(f"[{name}] oracle vs reference: logits {dl:.3e} offsets {do:.3e} cls {dc:.3e} fpn {df:.3e}")
     assert dl < 2e-4 and do < 2e-4 and dc < 2e-4, "oracle restatement disagrees with the reference"
@@ -146,7 +170,7 @@ def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_le
         segs_all.append(pad)
         scores_all.append(sp)
         n_all.append(k)
-        vc_all.append(res["video_cls"].numpy())
+        vc_all.append(res["video_cls"].numpy() if "video_cls" in res else np.zeros(1, np.float32))
     out.update(segments=np.stack(segs_all), scores=np.stack(scores_all), n_segments=np.asarray(n_all),
                video_cls=np.stack(vc_all), kept_points=np.stack(kept_all))
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
@@ -167,11 +191,12 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
     if hasattr(model, "interpolator"):
         model.interpolator.dp1.p = 0.0
     the = cfg["variant"] == "the"
+    plain = cfg["variant"] == "plain"
     x, mask = synth_inputs(cfg, lens, xseed)
     rs = np.random.RandomState(xseed + 7)
     vids, gts, gls, gfl = [], [], [], []
     for b, n in enumerate(lens):
-        if b % 2 == 0:
+        if b % 2 == 0 or plain:               # LocPointTransformer trains on clips with segments only
             k = 1 + b % 3
             st = np.sort(rs.uniform(0, n - 20, size=k)).astype(np.float32)
             ln = rs.uniform(2.0, 18.0, size=k).astype(np.float32)
@@ -198,8 +223,8 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
                               gt_frame_labels=gfl if the else None)
     ol["final_loss"].backward()
     recon = cfg["variant"] == "recon"
-    lkeys = ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss") + (("reco_seg_loss",) if the else ()) + \
-        (("reco_loss",) if recon else ())
+    lkeys = (("cls_loss", "reg_loss", "final_loss") if plain else ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")) + \
+        (("reco_seg_loss",) if the else ()) + (("reco_loss",) if recon else ())
     for k in lkeys:
         print(f"[{name}] {k}: ref {float(losses[k]):.6f} oracle {float(ol[k]):.6f}")
         assert abs(float(losses[k]) - float(ol[k])) < 1e-4 * max(1.0, abs(float(losses[k])))
@@ -209,7 +234,9 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
              "backbone.hh_branch.0.attn.key_norm.weight", "backbone.branch.1.drop_path_attn.scale",
              "neck.fpn_convs.3.conv.weight", "cls_head.cls_head.conv.bias", "reg_head.scale.2.scale",
              "reg_head.offset_head.conv.weight"]
-    if the:
+    if plain:
+        gkeys = [k for k in gkeys if "lh_branch" not in k and "hh_branch" not in k] + ["backbone.stem.1.mlp.0.weight"]
+    elif the:
         gkeys += ["segmentandCls.contraction.down_3.conv_block.conv.weight", "segmentandCls.conv0.0.weight",
                   "segmentandCls.seg_linear.weight", "segmentandCls.cls_linear1.weight",
                   "segmentandCls.cls_linear1.bias", "segmentandCls.contraction.down_1.conv_block.conv.bias"]
@@ -241,7 +268,7 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
         gt_segments=np.array([np.zeros((0, 2), np.float32) if g is None else g.numpy() for g in gts],
                              dtype=object),
         is_fake=np.array([g is not None for g in gts]),
-        losses=np.array([float(losses[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")]),
+        losses=np.array([float(losses[k]) if k in losses else 0.0 for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")]),
         reco_seg_loss=float(losses["reco_seg_loss"]) if the else 0.0,
         reco_loss=float(losses["reco_loss"]) if recon else 0.0,
         gt_frame_labels=np.array([np.zeros(0, np.float32) if f is None else f.numpy() for f in gfl], dtype=object),
@@ -473,6 +500,8 @@ def main():
     case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, ctx)          # full-size exp10, 4 clips
     case_forward("fwd_the_small", R.make_cfg(variant="the", **SMALL), [192, 133], 31, 32, ctx)
     case_train("train_the_small", R.make_cfg(variant="the", **SMALL), [192, 150, 180, 192], 33, 34, ctx)
+    case_forward("fwd_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 151], 51, 52, ctx)
+    case_train("train_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 150, 180, 192], 53, 54, ctx)
     case_forward("fwd_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 140], 41, 42, ctx)
     case_train("train_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 150, 180, 192], 43, 44, ctx)
     print("done")
@@ -487,6 +516,12 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, import_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "plain":
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        ctx = import_reference()
+        case_forward("fwd_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 151], 51, 52, ctx)
+        case_train("train_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 150, 180, 192], 53, 54, ctx)
     elif len(sys.argv) > 1 and sys.argv[1] == "nms_modes":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()

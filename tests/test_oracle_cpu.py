@@ -23,7 +23,8 @@ def synth_inputs(cfg, lens, seed):
 
 @pytest.mark.parametrize("name,over", [("fwd_small", SMALL), ("fwd_small_init", SMALL), ("fwd_mid", MID),
                                        ("fwd_the_small", dict(variant="the", **SMALL)),
-                                       ("fwd_recon_small", dict(variant="recon", **SMALL)), ("fwd_exp10", {})])
+                                       ("fwd_recon_small", dict(variant="recon", **SMALL)),
+                                       ("fwd_plain_small", dict(variant="plain", **SMALL)), ("fwd_exp10", {})])
 def test_oracle_forward_and_detections_match_reference(golden_dir, name, over):
     torch.set_num_threads(8)
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
@@ -48,7 +49,8 @@ def test_oracle_forward_and_detections_match_reference(golden_dir, name, over):
 
 @pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID),
                                        ("train_the_small", dict(variant="the", **SMALL)),
-                                       ("train_recon_small", dict(variant="recon", **SMALL))])
+                                       ("train_recon_small", dict(variant="recon", **SMALL)),
+                                       ("train_plain_small", dict(variant="plain", **SMALL))])
 def test_oracle_training_losses_and_gradients_match_reference(golden_dir, name, over):
     torch.set_num_threads(8)
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
@@ -65,7 +67,7 @@ def test_oracle_training_losses_and_gradients_match_reference(golden_dir, name, 
     out = R.model_forward(sd, cfg, x, mask, training=True)
     ol, norm, _ = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], x_in=x, gt_frame_labels=gfl if the else None)
     ol["final_loss"].backward()
-    got = np.array([float(ol[k]) for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
+    got = np.array([float(ol[k]) if k in ol else 0.0 for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
     assert np.allclose(got, g["losses"], rtol=1e-4, atol=1e-6), (got, g["losses"])
     assert abs(norm - float(g["loss_normalizer"])) < 1e-4
     for key in g.files:
