@@ -3,8 +3,8 @@ import torch
 from torch import nn
 
 from .models import register_backbone
-from .blocks import (MaskedConv1D, LayerNorm, TransformerBlock, MutilModelTransformerBlock, get_sinusoid_encoding,
-                     plan_drop_path)
+from .blocks import (MaskedConv1D, LayerNorm, TransformerBlock, MutilModelTransformerBlock, ConvBlock,
+                     get_sinusoid_encoding, plan_drop_path)
 from ... import ops
 
 
@@ -144,6 +144,44 @@ class ConvTransformerBackbone(nn.Module):
     def forward(self, x, mask):
         if self.training:
             plan_drop_path(self, x.shape[0], x.device)
+        x = self._embed(x, mask)
+        for blk in self.stem:
+            x, mask = blk(x, mask)
+        out_feats, out_masks = [x], [mask]
+        for blk in self.branch:
+            x, mask = blk(x, mask)
+            out_feats.append(x)
+            out_masks.append(mask)
+        return out_feats, out_masks
+
+
+@register_backbone("conv")
+class ConvBackbone(nn.Module):
+    """Convolution-only backbone (reference: libs/modeling/backbones.py:171-269): conv embedding (+LN, ReLU) -> stem
+    ConvBlocks -> strided branch ConvBlocks, one pyramid level per branch block."""
+
+    def __init__(self, n_in, n_embd, n_embd_ks, arch=(2, 2, 5), scale_factor=2, with_ln=False):
+        super().__init__()
+        assert len(arch) == 3 and not isinstance(n_in, (list, tuple)) and with_ln
+        self.n_in, self.arch, self.scale_factor = n_in, arch, scale_factor
+        self.use_abs_pe, self.proj = False, None
+        self.embd = nn.ModuleList()
+        self.embd_norm = nn.ModuleList()
+        for idx in range(arch[0]):
+            self.embd.append(MaskedConv1D(n_in if idx == 0 else n_embd, n_embd, n_embd_ks, stride=1,
+                                          padding=n_embd_ks // 2, bias=(not with_ln)))
+            self.embd_norm.append(LayerNorm(n_embd))
+        self.stem = nn.ModuleList([ConvBlock(n_embd, 3, 1) for _ in range(arch[1])])
+        self.branch = nn.ModuleList([ConvBlock(n_embd, 3, scale_factor) for _ in range(arch[2])])
+        self.apply(self.__init_weights__)
+
+    def __init_weights__(self, module):
+        if isinstance(module, (nn.Linear, nn.Conv1d)) and module.bias is not None:
+            torch.nn.init.constant_(module.bias, 0.)
+
+    _embed = ConvHRLRFullResSelfAttTransformerBackboneRevised._embed
+
+    def forward(self, x, mask):
         x = self._embed(x, mask)
         for blk in self.stem:
             x, mask = blk(x, mask)

@@ -359,6 +359,30 @@ class MutilModelTransformerBlock(_BlockBase):
         return self._residual_mlp(x_q, out, out_mask), out_mask
 
 
+class ConvBlock(nn.Module):
+    """ResNet-style basic block (blocks.py:1320-1370): conv k3 (stride s) -> ReLU -> conv k3, + identity (1x1 stride-s conv
+    when s > 1), ReLU.  The strided 1x1 conv is a row subsample followed by the 1x1 GEMM."""
+
+    def __init__(self, n_embd, kernel_size=3, n_ds_stride=1, expansion_factor=2, n_out=None, act_layer=nn.ReLU):
+        super().__init__()
+        assert kernel_size == 3 and act_layer is nn.ReLU and n_ds_stride in (1, 2)
+        n_out = n_embd if n_out is None else n_out
+        width = n_embd * expansion_factor
+        self.stride = n_ds_stride
+        self.conv1 = MaskedConv1D(n_embd, width, kernel_size, n_ds_stride, padding=1)
+        self.conv2 = MaskedConv1D(width, n_out, kernel_size, 1, padding=1)
+        self.downsample = MaskedConv1D(n_embd, n_out, 1, 1) if n_ds_stride > 1 else None   # stride applied by subsampling
+        self.register_buffer("_ones", torch.ones(n_out), persistent=False)
+
+    def forward(self, x, mask, pos_embd=None):
+        out, out_mask = self.conv1(x, mask, act=ops.ACT_RELU)
+        out, out_mask = self.conv2(out, out_mask)
+        identity = x
+        if self.downsample is not None:
+            identity, _ = self.downsample(ops.downsample(x, self.stride), out_mask)
+        return torch.relu(ops.affine_residual(out, None, identity, None, self._ones)), out_mask
+
+
 class DownBlock(nn.Module):
     """masked conv k3 (stride 2 by default) -> InstanceNorm1d -> LeakyReLU(0.2) (blocks.py:1495-1516)."""
 

@@ -182,7 +182,12 @@ class AVPtTransformerRecovery(nn.Module):
         self.test_voting_thresh = test_cfg['voting_thresh']
 
         assert backbone_type in self.BACKBONES, (backbone_type, self.BACKBONES)
-        self.backbone = make_backbone(backbone_type, **{
+        if backbone_type == 'conv':                        # meta_archs.py:271-281
+            self.backbone = make_backbone('conv', **{'n_in': input_dim, 'n_embd': embd_dim, 'n_embd_ks': embd_kernel_size,
+                                                     'arch': backbone_arch, 'scale_factor': scale_factor,
+                                                     'with_ln': embd_with_ln})
+        else:
+            self.backbone = make_backbone(backbone_type, **{
             'n_in': input_dim, 'n_embd': embd_dim, 'n_head': n_head, 'n_embd_ks': embd_kernel_size,
             'max_len': max_seq_len, 'arch': backbone_arch, 'mha_win_size': self.mha_win_size,
             'scale_factor': scale_factor, 'with_ln': embd_with_ln, 'attn_pdrop': 0.0,
@@ -431,7 +436,7 @@ class PtTransformer(AVPtTransformerRecovery):
     to carry segments (meta_archs.py:346-348); losses / results have the reference's keys (no `reco_cls_loss`, no
     `video_cls`)."""
 
-    BACKBONES = ('convTransformer',)
+    BACKBONES = ('convTransformer', 'conv')
 
     def __init__(self, backbone_type, fpn_type, backbone_arch, scale_factor, max_seq_len, max_buffer_len_factor, n_head,
                  n_mha_win_size, embd_kernel_size, embd_dim, embd_with_ln, fpn_dim, fpn_with_ln, fpn_start_level, head_dim,

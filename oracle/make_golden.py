@@ -46,13 +46,14 @@ def ref_model_plain(load_config, C, make_meta_arch, cfg):
     m = dict(rc["model"])
     m.pop("video_input_dim")
     m.pop("mlp_ratio", None)
-    m.update(backbone_type="convTransformer", input_dim=cfg["input_dim"], audio_input_dim=0, max_seq_len=cfg["max_seq_len"],
+    m.update(backbone_type="conv" if cfg["variant"] == "plainconv" else "convTransformer", input_dim=cfg["input_dim"],
+             audio_input_dim=0, max_seq_len=cfg["max_seq_len"],
              embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"], head_dim=cfg["head_dim"], n_head=cfg["n_head"])
     return make_meta_arch("LocPointTransformer", **m), rc
 
 
 def ref_model(load_config, C, make_meta_arch, yaml_name, cfg):
-    if cfg["variant"] == "plain":
+    if cfg["variant"] in ("plain", "plainconv"):
         return ref_model_plain(load_config, C, make_meta_arch, cfg)
     rc = load_config(f"{REF}/configs_train/{yaml_name}", defaults=copy.deepcopy(C.DEFAULTS))
     m = rc["model"]
@@ -113,7 +114,7 @@ def match_segments(seg_a, sc_a, seg_b, sc_b):
 
 def yaml_for(cfg):
     return {"norecon": "deepfake_exp10.yaml", "the": "deepfake_exp13.yaml", "recon": "deepfake_exp5.yaml",
-            "plain": "deepfake_exp10.yaml"}[cfg["variant"]]
+            "plain": "deepfake_exp10.yaml", "plainconv": "deepfake_exp10.yaml"}[cfg["variant"]]
 
 
 def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_levels=True):
@@ -191,7 +192,7 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
     if hasattr(model, "interpolator"):
         model.interpolator.dp1.p = 0.0
     the = cfg["variant"] == "the"
-    plain = cfg["variant"] == "plain"
+    plain = cfg["variant"] in ("plain", "plainconv")
     x, mask = synth_inputs(cfg, lens, xseed)
     rs = np.random.RandomState(xseed + 7)
     vids, gts, gls, gfl = [], [], [], []
@@ -234,7 +235,11 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
              "backbone.hh_branch.0.attn.key_norm.weight", "backbone.branch.1.drop_path_attn.scale",
              "neck.fpn_convs.3.conv.weight", "cls_head.cls_head.conv.bias", "reg_head.scale.2.scale",
              "reg_head.offset_head.conv.weight"]
-    if plain:
+    if cfg["variant"] == "plainconv":
+        gkeys = ["backbone.embd.0.conv.weight", "backbone.stem.0.conv1.conv.weight", "backbone.stem.1.conv2.conv.bias",
+                 "backbone.branch.2.downsample.conv.weight", "backbone.branch.4.conv1.conv.weight", "neck.fpn_convs.3.conv.weight",
+                 "cls_head.cls_head.conv.bias", "reg_head.scale.2.scale", "reg_head.offset_head.conv.weight"]
+    elif plain:
         gkeys = [k for k in gkeys if "lh_branch" not in k and "hh_branch" not in k] + ["backbone.stem.1.mlp.0.weight"]
     elif the:
         gkeys += ["segmentandCls.contraction.down_3.conv_block.conv.weight", "segmentandCls.conv0.0.weight",
@@ -502,6 +507,8 @@ def main():
     case_train("train_the_small", R.make_cfg(variant="the", **SMALL), [192, 150, 180, 192], 33, 34, ctx)
     case_forward("fwd_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 151], 51, 52, ctx)
     case_train("train_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 150, 180, 192], 53, 54, ctx)
+    case_forward("fwd_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 133], 61, 62, ctx)
+    case_train("train_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 150, 180, 192], 63, 64, ctx)
     case_forward("fwd_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 140], 41, 42, ctx)
     case_train("train_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 150, 180, 192], 43, 44, ctx)
     print("done")
@@ -516,6 +523,12 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, import_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == "plainconv":
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        ctx = import_reference()
+        case_forward("fwd_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 133], 61, 62, ctx)
+        case_train("train_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 150, 180, 192], 63, 64, ctx)
     elif len(sys.argv) > 1 and sys.argv[1] == "plain":
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)

@@ -18,14 +18,16 @@ TOL = 1e-3
 
 
 YAML = {"norecon": "deepfake_exp10.yaml", "the": "deepfake_exp13.yaml", "recon": "deepfake_exp5.yaml",
-        "plain": "deepfake_exp10.yaml"}
+        "plain": "deepfake_exp10.yaml", "plainconv": "deepfake_exp10.yaml"}
 
 
 def build(cfg_over, wseed, trained_like=True):
     from audio_visual_deepfake_detection_amd import build_model
     from oracle import ummaformer_ref as R
     cfg = R.make_cfg(**cfg_over)
-    extra = dict(model_name="LocPointTransformer", backbone_type="convTransformer") if cfg["variant"] == "plain" else {}
+    extra = {}
+    if cfg["variant"] in ("plain", "plainconv"):
+        extra = dict(model_name="LocPointTransformer", backbone_type="conv" if cfg["variant"] == "plainconv" else "convTransformer")
     model, _ = build_model(YAML[cfg["variant"]], video_input_dim=8, audio_input_dim=cfg["input_dim"] - 8,
                            max_seq_len=cfg["max_seq_len"], embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"],
                            head_dim=cfg["head_dim"], n_head=cfg["n_head"], **extra)
@@ -66,11 +68,13 @@ def maxerr(a, b):
 THE_SMALL = dict(variant="the", **SMALL)
 RECON_SMALL = dict(variant="recon", **SMALL)
 PLAIN_SMALL = dict(variant="plain", **SMALL)          # LocPointTransformer + convTransformer backbone
+CONV_SMALL = dict(variant="plainconv", **SMALL)       # LocPointTransformer + conv backbone
 
 
 @pytest.mark.parametrize("name,over", [("fwd_small", SMALL), ("fwd_small_init", SMALL), ("fwd_mid", MID),
                                        ("fwd_exp10", {}), ("fwd_the_small", THE_SMALL),
-                                       ("fwd_recon_small", RECON_SMALL), ("fwd_plain_small", PLAIN_SMALL)])
+                                       ("fwd_recon_small", RECON_SMALL), ("fwd_plain_small", PLAIN_SMALL),
+                                       ("fwd_conv_small", CONV_SMALL)])
 def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
     model, sd, cfg = build(over, int(g["wseed"]), bool(int(g["trained_like"])))
@@ -111,6 +115,7 @@ def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID), ("train_the_small", THE_SMALL),
                                        ("train_recon_small", RECON_SMALL), ("train_plain_small", PLAIN_SMALL),
+                                       ("train_conv_small", CONV_SMALL),
                                        ("train_exp10", {})])        # {} = full-size exp10
 def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name, over, accumulate):
     """accumulate=False: deterministic slab reductions, autograd owns the gradients.
