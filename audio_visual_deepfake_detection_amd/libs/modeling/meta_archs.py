@@ -473,3 +473,13 @@ class PtTransformer(AVPtTransformerRecovery):
         for r in results:
             r.pop('video_cls')
         return results
+
+
+@register_meta_arch("AVLocPointTransformer")
+class AVPtTransformer(PtTransformer):
+    """Reference: libs/modeling/av_meta_arch.py:162-700 -- LocPointTransformer on the channel-concatenated audio-visual
+    input (`input_dim + audio_input_dim`, av_meta_arch.py:198); same modules, state-dict keys, losses and outputs."""
+
+    def __init__(self, *args, input_dim=None, audio_input_dim=0, video_input_dim=None, **kw):
+        base = input_dim if input_dim is not None else video_input_dim
+        super().__init__(*args, input_dim=int(base) + int(audio_input_dim or 0), audio_input_dim=0, **kw)

@@ -273,3 +273,17 @@ def test_device_prefetcher_feeds_identical_batches(tmp_path):
         assert torch.equal(x, x_ref) and torch.equal(m, m_ref)
         n += 1
     assert n == len(plain) == 3
+
+
+def test_av_loc_point_transformer_is_the_plain_model_on_concatenated_input():
+    """`AVLocPointTransformer` (av_meta_arch.py:162) == `LocPointTransformer` with input_dim + audio_input_dim channels."""
+    from audio_visual_deepfake_detection_amd import build_model
+    kw = dict(max_seq_len=192, embd_dim=32, fpn_dim=32, head_dim=32, n_head=4, backbone_type="convTransformer")
+    a, _ = build_model("deepfake_exp10.yaml", model_name="AVLocPointTransformer", video_input_dim=8, audio_input_dim=88, **kw)
+    b, _ = build_model("deepfake_exp10.yaml", model_name="LocPointTransformer", video_input_dim=96, audio_input_dim=0, **kw)
+    assert [k for k in a.state_dict()] == [k for k in b.state_dict()]
+    b.load_state_dict(a.state_dict())
+    a, b = a.to("cuda:0").eval(), b.to("cuda:0").eval()
+    clip = dict(video_id="v", feats=torch.randn(96, 150), fps=25.0, duration=6.0, feat_stride=1.0, feat_num_frames=1.0)
+    ra, rb = a([clip])[0], b([clip])[0]
+    assert torch.equal(ra["segments"], rb["segments"]) and torch.equal(ra["scores"], rb["scores"]) and "video_cls" not in ra
