@@ -293,6 +293,9 @@ __global__ __launch_bounds__(1024) void reduce_segments_kernel(const float* __re
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 constexpr int kTile = 32, kWaves = 8;
+// backward: 16-token tiles -> twice the workgroups, 76 KB of LDS each (2 per CU): the three branches of a tile are
+// processed one after the other, so co-resident workgroups are what hides the load latency
+constexpr int kTileB = 16, kWavesB = 8;
 
 }  // namespace
 
@@ -332,8 +335,8 @@ extern "C" int avdf_chain_fwd(const float* const* x, const float* const* gamma_a
   return AVDF_OK;
 }
 
-extern "C" int64_t avdf_chain_bwd_ws(int B, int Tin, int C) { return (int64_t)B * cdiv(Tin, kTile) * 21 * C; }
-extern "C" int avdf_chain_bwd_rows(int B, int Tin) { return B * cdiv(Tin, kTile); }
+extern "C" int64_t avdf_chain_bwd_ws(int B, int Tin, int C) { return (int64_t)B * cdiv(Tin, kTileB) * 21 * C; }
+extern "C" int avdf_chain_bwd_rows(int B, int Tin) { return B * cdiv(Tin, kTileB); }
 
 extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, const float* const* stats_b,
                               const float* const* x, const float* const* stats_a, const float* const* gamma_a,
@@ -356,15 +359,15 @@ extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, con
     a.ga[i] = gamma_a[i]; a.ba[i] = beta_a[i]; a.w[i] = w[i]; a.gb[i] = gamma_b[i]; a.dx[i] = dx[i];
   }
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = cdiv(Tin, kTile);
+  const int tiles = cdiv(Tin, kTileB);
   if (stride == 1) {
-    constexpr int RU = kTile + 2;
-    hipLaunchKernelGGL((chain_bwd_kernel<1, kTile, kWaves>), dim3(B * tiles), dim3(64 * kWaves),
-                       (size_t)(RU + kWaves * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
+    constexpr int RU = kTileB + 2;
+    hipLaunchKernelGGL((chain_bwd_kernel<1, kTileB, kWavesB>), dim3(B * tiles), dim3(64 * kWavesB),
+                       (size_t)(RU + kWavesB * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
   } else {
-    constexpr int RU = kTile / 2 + 2;
-    hipLaunchKernelGGL((chain_bwd_kernel<2, kTile, kWaves>), dim3(B * tiles), dim3(64 * kWaves),
-                       (size_t)(RU + kWaves * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
+    constexpr int RU = kTileB / 2 + 2;
+    hipLaunchKernelGGL((chain_bwd_kernel<2, kTileB, kWavesB>), dim3(B * tiles), dim3(64 * kWavesB),
+                       (size_t)(RU + kWavesB * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
   }
   AVDF_CHECK_LAUNCH("chain_bwd");
   return AVDF_OK;

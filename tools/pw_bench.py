@@ -40,3 +40,21 @@ us = timeit(lambda: check(lib.avdf_local_attn_fwd(P(q), P(k), P(v), P(mask), P(o
 print(f"local_attn_fwd: {us:.2f} us")
 us = timeit(lambda: check(lib.avdf_local_attn_bwd(P(dy), P(q), P(k), P(v), P(probs), P(dq), P(dk), P(dv), P(wsa), B, T, H, hs, W, 0.125, st()), "lab"))
 print(f"local_attn_bwd (2 kernels): {us:.2f} us")
+# fused q/k/v chains
+from audio_visual_deepfake_detection_amd import ops as O
+xs = [x, x, x]
+ga = [g] * 3; ba = [b] * 3
+wd = [torch.randn(C, 1, 3, device=dev) for _ in range(3)]
+gb = [torch.randn(C, device=dev) for _ in range(3)]; bb = [torch.randn(C, device=dev) for _ in range(3)]
+u3 = [torch.empty_like(x) for _ in range(3)]; y3 = [torch.empty_like(x) for _ in range(3)]
+sa = torch.empty(3, 2, B * T, device=dev); sb = torch.empty(3, 2, B * T, device=dev)
+PT = O._ptr_table
+fwd = lambda: check(lib.avdf_chain_fwd(PT(xs), PT(ga), PT(ba), PT(wd), PT(gb), PT(bb), P(mask), PT(u3), PT(y3), PT([sa[0], sa[1], sa[2]]),
+                                       PT([sb[0], sb[1], sb[2]]), B, T, T, C, 1, 1e-5, st()), "cf")
+print(f"chain_fwd: {timeit(fwd):.2f} us")
+dys = [torch.randn_like(x) for _ in range(3)]; dxs = [None, None, torch.empty_like(x)]
+wsb = torch.empty(int(lib.avdf_chain_bwd_ws(B, T, C)), device=dev)
+bwd = lambda: check(lib.avdf_chain_bwd(PT(dys), PT(u3), PT([sb[0], sb[1], sb[2]]), PT(xs), PT([sa[0], sa[1], sa[2]]), PT(ga), PT(ba), PT(wd),
+                                       PT(gb), P(mask), PT(dxs), 4, P(wsb), B, T, T, C, 1, st()), "cb")
+fwd()
+print(f"chain_bwd: {timeit(bwd):.2f} us")
