@@ -143,10 +143,20 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
 }
 
 // one workgroup per (b, 64-channel group); 256 threads = 64 channels x 4 time slices
-__global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(
+// InstanceNorm kernels: 64 channels x kInG time-groups per workgroup (the time loop is latency-bound: 16 groups keep
+// 4x more rows in flight than the original 4)
+constexpr int kInG = 16;
+__device__ __forceinline__ float in_sum(const float (*red)[64], int cl) {
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < kInG; ++q) s += red[q][cl];
+  return s;
+}
+
+__global__ __launch_bounds__(64 * kInG) void instnorm_lrelu_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
     int T, int C, float eps, float slope) {
-  __shared__ float red[4][64];
+  __shared__ float red[kInG][64];
   __shared__ float stat[2][64];
   const int cl = threadIdx.x & 63, ts = threadIdx.x >> 6;
   const int groups = (C + 63) / 64;
@@ -154,34 +164,34 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(
   const bool ok = c < C;
   const float* xb = x + (size_t)b * T * C + c;
   float s = 0.f;
-  if (ok) for (int t = ts; t < T; t += 4) s += xb[(size_t)t * C];
+  if (ok) for (int t = ts; t < T; t += kInG) s += xb[(size_t)t * C];
   red[ts][cl] = s;
   __syncthreads();
-  if (ts == 0) stat[0][cl] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)T;
+  if (ts == 0) stat[0][cl] = in_sum(red, cl) / (float)T;
   __syncthreads();
   const float mean = stat[0][cl];
   float q = 0.f;
-  if (ok) for (int t = ts; t < T; t += 4) { const float d = xb[(size_t)t * C] - mean; q += d * d; }
+  if (ok) for (int t = ts; t < T; t += kInG) { const float d = xb[(size_t)t * C] - mean; q += d * d; }
   red[ts][cl] = q;
   __syncthreads();
   if (ts == 0) {
-    const float var = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)T;
+    const float var = in_sum(red, cl) / (float)T;
     stat[1][cl] = 1.0f / sqrtf(var + eps);
     if (ok && mean_o) { mean_o[(size_t)b * C + c] = mean; rstd_o[(size_t)b * C + c] = stat[1][cl]; }
   }
   __syncthreads();
   const float rstd = stat[1][cl];
   float* yb = y + (size_t)b * T * C + c;
-  if (ok) for (int t = ts; t < T; t += 4) {
+  if (ok) for (int t = ts; t < T; t += kInG) {
     const float h = (xb[(size_t)t * C] - mean) * rstd;
     yb[(size_t)t * C] = h > 0.f ? h : h * slope;
   }
 }
 
-__global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(
+__global__ __launch_bounds__(64 * kInG) void instnorm_lrelu_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, float* __restrict__ dx, int T, int C, float slope) {
-  __shared__ float red[2][4][64];
+  __shared__ float red[2][kInG][64];
   const int cl = threadIdx.x & 63, ts = threadIdx.x >> 6;
   const int groups = (C + 63) / 64;
   const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * 64 + cl;
@@ -189,16 +199,16 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(
   const size_t base = (size_t)b * T * C + c;
   const float mean = ok ? mean_i[(size_t)b * C + c] : 0.f, rstd = ok ? rstd_i[(size_t)b * C + c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  if (ok) for (int t = ts; t < T; t += 4) {
+  if (ok) for (int t = ts; t < T; t += kInG) {
     const float h = (x[base + (size_t)t * C] - mean) * rstd;
     const float g = dy[base + (size_t)t * C] * (h > 0.f ? 1.f : slope);
     s1 += g; s2 += g * h;
   }
   red[0][ts][cl] = s1; red[1][ts][cl] = s2;
   __syncthreads();
-  const float m1 = (red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]) / (float)T;
-  const float m2 = (red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]) / (float)T;
-  if (ok) for (int t = ts; t < T; t += 4) {
+  const float m1 = in_sum(red[0], cl) / (float)T;
+  const float m2 = in_sum(red[1], cl) / (float)T;
+  if (ok) for (int t = ts; t < T; t += kInG) {
     const float h = (x[base + (size_t)t * C] - mean) * rstd;
     const float g = dy[base + (size_t)t * C] * (h > 0.f ? 1.f : slope);
     dx[base + (size_t)t * C] = rstd * (g - m1 - h * m2);
@@ -426,7 +436,7 @@ extern "C" int avdf_instnorm_lrelu_fwd(const float* x, float* y, float* mean, fl
                                        int B, int T, int C, float eps, float slope, void* stream) {
   AVDF_REQUIRE(x && y && B > 0 && T > 0 && C > 0, "instnorm_lrelu_fwd: bad args");
   AVDF_REQUIRE((mean == nullptr) == (rstd == nullptr), "instnorm_lrelu_fwd: mean/rstd");
-  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(B * cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(B * cdiv(C, 64)), dim3(64 * kInG), 0, (hipStream_t)stream,
                      x, y, mean, rstd, T, C, eps, slope);
   AVDF_CHECK_LAUNCH("instnorm_lrelu_fwd");
   return AVDF_OK;
@@ -435,7 +445,7 @@ extern "C" int avdf_instnorm_lrelu_fwd(const float* x, float* y, float* mean, fl
 extern "C" int avdf_instnorm_lrelu_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                        float* dx, int B, int T, int C, float slope, void* stream) {
   AVDF_REQUIRE(dy && x && mean && rstd && dx && B > 0 && T > 0 && C > 0, "instnorm_lrelu_bwd: bad args");
-  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(B * cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(B * cdiv(C, 64)), dim3(64 * kInG), 0, (hipStream_t)stream,
                      dy, x, mean, rstd, dx, T, C, slope);
   AVDF_CHECK_LAUNCH("instnorm_lrelu_bwd");
   return AVDF_OK;
