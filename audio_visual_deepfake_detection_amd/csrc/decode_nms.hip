@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int kMaxP = 2048;
+constexpr int kNT = 1024;      // threads per clip: the sort / suppression / voting loops are barrier-bound, 16 waves cut their trip counts 4x
 
 struct Cand { float score; int idx; };
 
@@ -20,7 +21,7 @@ __device__ __forceinline__ bool before(const Cand& a, const Cand& b) {   // a ra
   return a.score > b.score || (a.score == b.score && a.idx < b.idx);
 }
 
-__global__ __launch_bounds__(256) void decode_nms_kernel(
+__global__ __launch_bounds__(kNT) void decode_nms_kernel(
     const float* __restrict__ points, const float* __restrict__ logits, const float* __restrict__ offsets,
     const float* __restrict__ pmask, float* __restrict__ out_segs, float* __restrict__ out_scores,
     int32_t* __restrict__ out_pidx, int32_t* __restrict__ out_count, int P,
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(
   __syncthreads();
 
   int lc = 0, ln = 0;
-  for (int p = tid; p < kMaxP; p += 256) {
+  for (int p = tid; p < kMaxP; p += kNT) {
     Cand c; c.score = -1.f; c.idx = p;
     if (p < P) {
       const float x = logits[(size_t)b * P + p];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(
   // bitonic sort of 2048 keys, rank order = `before`
   for (int k = 2; k <= kMaxP; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < kMaxP; i += 256) {
+      for (int i = tid; i < kMaxP; i += kNT) {
         const int l = i ^ j;
         if (l > i) {
           const Cand a = key[i], c = key[l];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(
   }
 
   const int nn = n_nms;      // candidates with score > min_score occupy ranks [0, nn)
-  for (int i = tid; i < kMaxP; i += 256) alive[i] = i < nn ? 1 : 0;
+  for (int i = tid; i < kMaxP; i += kNT) alive[i] = i < nn ? 1 : 0;
   __syncthreads();
 
   // greedy NMS in rank order; only the first max_seg survivors are ever reported
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(
     const int pi = key[i].idx;
     const float ix1 = s0[pi], ix2 = s1[pi];
     const float ia = ix2 - ix1 + 1e-6f;
-    for (int j = i + 1 + tid; j < nn; j += 256) {
+    for (int j = i + 1 + tid; j < nn; j += kNT) {
       if (!alive[j]) continue;
       const int pj = key[j].idx;
       const float xx1 = fmaxf(ix1, s0[pj]), xx2 = fminf(ix2, s1[pj]);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(
   const int nc = n_cand;     // voting pool = every decoded candidate (ranks [0, nc)), nms.py:176-182
 
   const int lane = tid & 63, wid = tid >> 6;
-  for (int q = wid; q < nk; q += 4) {
+  for (int q = wid; q < nk; q += kNT / 64) {
     const int ri = kept[q];
     const int pi = key[ri].idx;
     float a0 = s0[pi], a1 = s1[pi];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(
       out_pidx[(size_t)b * max_seg + q] = pi;
     }
   }
-  for (int q = nk + tid; q < max_seg; q += 256) {
+  for (int q = nk + tid; q < max_seg; q += kNT) {
     out_segs[((size_t)b * max_seg + q) * 2] = 0.f;
     out_segs[((size_t)b * max_seg + q) * 2 + 1] = 0.f;
     out_scores[(size_t)b * max_seg + q] = 0.f;
@@ -154,7 +155,7 @@ extern "C" int avdf_decode_nms(const float* points, const float* logits, const f
   AVDF_REQUIRE(points && logits && offsets && pmask && out_segs && out_scores && out_pidx && out_count, "decode_nms: null pointer");
   AVDF_REQUIRE(B > 0 && P > 0 && P <= kMaxP, "decode_nms: P=%d must be in 1..%d", P, kMaxP);
   AVDF_REQUIRE(max_seg > 0 && max_seg <= 256, "decode_nms: max_seg=%d must be in 1..256", max_seg);
-  hipLaunchKernelGGL(decode_nms_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, points, logits, offsets, pmask,
+  hipLaunchKernelGGL(decode_nms_kernel, dim3(B), dim3(kNT), 0, (hipStream_t)stream, points, logits, offsets, pmask,
                      out_segs, out_scores, out_pidx, out_count, P, pre_nms_thresh, duration_thresh, min_score,
                      iou_thr, voting_thr, max_seg);
   AVDF_CHECK_LAUNCH("decode_nms");
