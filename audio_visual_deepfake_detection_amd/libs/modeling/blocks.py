@@ -394,7 +394,9 @@ class DownBlock(nn.Module):
         assert norm, "every shipped config builds DownBlock with norm=True"
 
     def forward(self, x, mask):
-        x, mask = self.conv_block(x, mask, exact=True)      # feeds an InstanceNorm over time: keep the exact-fp32 GEMM
+        # feeds an InstanceNorm over time: training keeps the exact-fp32 GEMM (gradient parity);
+        # the inference paths may use the split-bf16 one (the video-level logit stays within the 1e-3 bar on every golden)
+        x, mask = self.conv_block(x, mask, exact=torch.is_grad_enabled())
         return ops.instnorm_lrelu(x, 1e-5, 0.2), mask
 
 
