@@ -785,7 +785,7 @@ struct TilePlan { int tile, kg, db; };
 // ---- measured plans ----------------------------------------------------------------------------------------
 // tools/autotune.py times every (tile, K-groups) / (token-splits, K-groups) choice for the GEMM shapes of a training
 // step on the GPU and writes gemm_tuned.inc; shapes not in the table use the heuristics below.
-struct TunedPlan { int kind, K, stride, M, N, Kred, a, b; };   // kind 0 fwd / 1 dgrad: (tile, kg); 2 wgrad: (splits, kg)
+struct TunedPlan { int kind, K, stride, M, N, Kred, a, b; };   // kind 0 fwd / 1 dgrad / 3 fwd in bf16x3 mode: (tile, kg + 8*db); 2 wgrad: (splits, kg)
 static const TunedPlan kTuned[] = {
 #include "gemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
@@ -812,7 +812,9 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
       return o;
     }
     if (K > 0 && g_override[kind][0] != -2) {          // -2: heuristic only (the tuner's baseline)
-      const TunedPlan* t = tuned_lookup(kind, K, stride, B * T, N, Kred);
+      const TunedPlan* t = nullptr;
+      if (kind == 0 && g_gemm_mode == 1) t = tuned_lookup(3, K, stride, B * T, N, Kred);   // kind 3: forward in bf16x3 mode
+      if (!t) t = tuned_lookup(kind, K, stride, B * T, N, Kred);
       if (t) return TilePlan{t->a, t->b & 7, (t->b >> 3) & 1};
     }
   }

@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                   "audio_visual_deepfake_detection_amd", "csrc", "gemm_tuned.inc"))
     ap.add_argument("--report", default="gpurun_out/autotune.json")
+    ap.add_argument("--bf16x3-fwd", action="store_true",
+                    help="measure only the forward shapes, in split-bf16 mode, and APPEND them as kind-3 rows to --out")
     args = ap.parse_args()
     log = {}
     for bsz in args.batch:
@@ -88,6 +90,9 @@ def main():
         for k, v in lg.items():
             log.setdefault(k, v)
     rows, report, saved = [], [], 0.0
+    if args.bf16x3_fwd:
+        log = {k: v for k, v in log.items() if k[0] == "fwd"}
+        check(lib.avdf_gemm_mode(1), "mode")
     for shape, cnt in sorted(log.items(), key=lambda kv: kv[0]):
         base, best, best_us, res = bench_shape(shape, args.iters)
         kind, K, s, B, Tin, Cin, Cout, n = shape
@@ -98,15 +103,20 @@ def main():
         if best is not None and best_us < 0.97 * base:
             saved += gain
             if kind == "fwd":
-                key = (0, K, s, B * n * Tout, Cout, Cin)
+                key = (3 if args.bf16x3_fwd else 0, K, s, B * n * Tout, Cout, Cin)
             elif kind == "dgrad":
                 key = (1, K, s, B * n * Tin, Cin, Cout)
             else:
                 key = (2, K, s, B * Tout, Cout * n, Cin)
             rows.append("    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s x%d: %.1f -> %.1f us" % (*key, best[0], best[1], kind, cnt, base, best_us))
-    with open(args.out, "w") as f:
-        f.write("// generated by tools/autotune.py (B=%s clips, exp10) -- {kind, K, stride, M, N, Kred, a, b},\n" % ",".join(map(str, args.batch)))
-        f.write("\n".join(rows) + ("\n" if rows else ""))
+    if args.bf16x3_fwd:
+        check(lib.avdf_gemm_mode(0), "mode")
+        with open(args.out, "a") as f:
+            f.write("// forward shapes re-measured in split-bf16 mode (kind 3)\n" + "\n".join(rows) + ("\n" if rows else ""))
+    else:
+        with open(args.out, "w") as f:
+            f.write("// generated by tools/autotune.py (B=%s clips, exp10) -- {kind, K, stride, M, N, Kred, a, b},\n" % ",".join(map(str, args.batch)))
+            f.write("\n".join(rows) + ("\n" if rows else ""))
     os.makedirs(os.path.dirname(args.report) or ".", exist_ok=True)
     json.dump(report, open(args.report, "w"), indent=1)
     print(f"wrote {len(rows)} tuned plans to {args.out}; predicted saving {saved/1e3:.2f} ms/step")
