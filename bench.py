@@ -69,6 +69,19 @@ def pmc_traffic(tag):
         return None
 
 
+def pmc_mfma_util(tag):
+    """MFMA-pipe utilisation of the kernel class `tag` (SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x un-instrumented
+    launch duration x 2.4 GHz); tools/pmc_mfma.py) from the committed PMC pass -- or None."""
+    path = os.path.join(ROOT, "profiles", "r01_g_pmc_mfma_util.json")
+    try:
+        d = json.load(open(path))
+        tag = tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad")
+        return {"kernel": d["by_tag"][tag]["mfma_util"], "all_conv_kernels": d["all_conv_kernels"],
+                "source": "profiles/r01_g_pmc_mfma_util.json"}
+    except Exception:
+        return None
+
+
 def conv_flops_per_clip(cfg_T=768, Cin=3072, D=256):
     """Necessary forward MFMA work per clip (21.58 GF; x3 for fwd+bwd)."""
     return 21.58e9
@@ -247,7 +260,7 @@ def main():
         ach = fl / tsec / 1e12
         roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(tag),
-                "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
+                "mfma_util": pmc_mfma_util(tag), "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
                 "flops_per_launch": round(fl / cnt),
                 "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2),
                                      "frac": round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

@@ -7,7 +7,7 @@
    avdf_gemm_override, `iters` launches captured in one hipGraph (L2-warm steady state, no host gaps);
 3. keeps a tuned entry only where it beats the heuristic plan by > 3 %, writes the table and a JSON report.
 Rebuild the library afterwards (python audio_visual_deepfake_detection_amd/csrc/build.py)."""
-import argparse, json, os, sys
+import os, argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from audio_visual_deepfake_detection_amd import build_model, ops
@@ -111,7 +111,10 @@ def main():
             rows.append("    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s x%d: %.1f -> %.1f us" % (*key, best[0], best[1], kind, cnt, base, best_us))
     if args.bf16x3_fwd:
         check(lib.avdf_gemm_mode(0), "mode")
-        with open(args.out, "a") as f:
+        cur = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "audio_visual_deepfake_detection_amd", "csrc", "gemm_tuned.inc")
+        keep = [l for l in open(cur).read().splitlines() if not l.startswith("{3,") and "(kind 3)" not in l]
+        with open(args.out, "w") as f:              # the table in the tree minus its old kind-3 rows, then the new ones
+            f.write("\n".join(keep) + "\n")
             f.write("// forward shapes re-measured in split-bf16 mode (kind 3)\n" + "\n".join(rows) + ("\n" if rows else ""))
     else:
         with open(args.out, "w") as f:
