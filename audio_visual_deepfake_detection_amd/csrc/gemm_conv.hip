@@ -401,10 +401,20 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 // data gradient
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false>
-__global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
-    DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
-  const int prob = blockIdx.z;
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB>
+constexpr int dgrad_smem_floats() {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  constexpr int RA = (BM + KS - 2) / S + 2;
+  constexpr int TILE = round4(round4(RA * (KC + 1)) + KC * BN * KS);
+  return cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
+}
+
+// body of one dgrad workgroup; (bx, by, bz) = the workgroup's coordinates in the (B*tilesT, c-tiles, problems) grid
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB>
+__device__ __forceinline__ void conv_dgrad_body(
+    float* __restrict__ smem, const DgradPtrs& ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT,
+    int bx, int by, int bz) {
+  const int prob = bz;
   const float* __restrict__ dy = pick3(ptrs.dy, prob);
   const float* __restrict__ w = pick3(ptrs.w, prob);
   const float* __restrict__ mask = pick3(ptrs.mask, prob);
@@ -421,9 +431,8 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (KC * B4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = KC * LDB;
   constexpr int TILE = round4(AS + BSZ);
-  constexpr int SM = cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
+  static_assert(dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB>() == cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4)), "smem size");
   constexpr int KCG = KC / KG;
-  __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
   float* Bs = smem + AS;
 
@@ -431,8 +440,8 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   const int kg = wid >> 2, w4 = wid & 3;
   const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.x / tilesT, tp0 = (blockIdx.x % tilesT) * BM;
-  const int c0 = blockIdx.y * BN;
+  const int b = bx / tilesT, tp0 = (bx % tilesT) * BM;
+  const int c0 = by * BN;
   const int tA0 = floordiv(tp0 + P - (KS - 1), S);
 
   floatx16 acc[MI * NI];
@@ -557,14 +566,29 @@ __global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
   });
 }
 
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false>
+__global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
+    DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
+  __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB>()];
+  conv_dgrad_body<KS, S, WM, WN, MI, NI, KC, KG, DB>(smem, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, blockIdx.x,
+                                                     blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight gradient (token dimension split over gridDim.z AND over the K-groups of a workgroup)
 // ------------------------------------------------------------------------------------------
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG>
+constexpr int wgrad_smem_floats() {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  return cmax(KT * BM + ((KT - 1) * S + KS) * BN, (KG - 1) * 4 * MI * NI * KS * 1024);
+}
+
+// body of one wgrad workgroup; (bx, by, bz) = coordinates in the (mtiles*problems, c-tiles, token splits) grid, gz = splits
 template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC>
-__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
-    WgradPtrs ptrs, int mtiles, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip,
-    int tilesPerSplit, int accumulate) {
-  const int prob = blockIdx.x / mtiles;
+__device__ __forceinline__ void conv_wgrad_body(
+    float* __restrict__ smem, const WgradPtrs& ptrs, int mtiles, int B, int Tin, int Cin, int Tout, int Cout, int act,
+    int tilesPerClip, int tilesPerSplit, int accumulate, int bx, int by, int bz, int gz) {
+  const int prob = bx / mtiles;
   const float* __restrict__ dy = pick3(ptrs.dy, prob);
   const float* __restrict__ x = pick3(ptrs.x, prob);
   const float* __restrict__ mask = pick3(ptrs.mask, prob);
@@ -580,9 +604,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
   constexpr int NY = (KT * Y4 + NT - 1) / NT, NX = (RX * X4 + NT - 1) / NT;
   constexpr int NACC = MI * NI * KS;
   constexpr int YS = KT * BM, XS = RX * BN;
-  constexpr int SM = cmax(YS + XS, (KG - 1) * 4 * NACC * 1024);
+  static_assert(wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG>() == cmax(YS + XS, (KG - 1) * 4 * NACC * 1024), "smem size");
   constexpr int KTG = KT / KG;
-  __shared__ __attribute__((aligned(16))) float smem[SM];
   float* Ys = smem;
   float* Xs = smem + YS;
 
@@ -590,8 +613,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
   const int kg = wid >> 2, w4 = wid & 3;
   const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = (blockIdx.x % mtiles) * BM, c0 = blockIdx.y * BN;
-  const int gbeg = blockIdx.z * tilesPerSplit;
+  const int n0 = (bx % mtiles) * BM, c0 = by * BN;
+  const int gbeg = bz * tilesPerSplit;
   int gend = gbeg + tilesPerSplit;
   const int gtot = B * tilesPerClip;
   if (gend > gtot) gend = gtot;
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
   };
 
   // ATOMIC path: the c-tile-0 workgroups also fold the bias gradient (column sums of the g tile)
-  const bool do_bias = ATOMIC && dbias != nullptr && blockIdx.y == 0 && tid < BM;
+  const bool do_bias = ATOMIC && dbias != nullptr && by == 0 && tid < BM;
   float bsum = 0.f;
 
   if (gbeg < gend) {
@@ -685,8 +708,8 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
   kgroup_reduce<NACC, KG>(acc, smem, kg, w4, lane);
   if (kg != 0) return;
 
-  float* o = out + ((!ATOMIC && gridDim.z > 1) ? (size_t)blockIdx.z * Cout * Cin * KS : 0);
-  const bool add = accumulate && gridDim.z == 1;
+  float* o = out + ((!ATOMIC && gz > 1) ? (size_t)bz * Cout * Cin * KS : 0);
+  const bool add = accumulate && gz == 1;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -706,6 +729,38 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
         }
       }
     }
+}
+
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC>
+__global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
+    WgradPtrs ptrs, int mtiles, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip,
+    int tilesPerSplit, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG>()];
+  conv_wgrad_body<KS, S, WM, WN, MI, NI, KT, KG, ATOMIC>(smem, ptrs, mtiles, B, Tin, Cin, Tout, Cout, act, tilesPerClip,
+                                                         tilesPerSplit, accumulate, blockIdx.x, blockIdx.y, blockIdx.z,
+                                                         gridDim.z);
+}
+
+// K=1 data gradient AND weight gradient of the same layer(s) in ONE launch: workgroups [0, nW) run the wgrad body
+// (token-split, atomics into dw / dbias), workgroups [nW, nW + nD) the dgrad body.  Both read the same dy; issued as
+// one grid they fill the chip together instead of leaving two under-filled launches with a drain between them.
+template <int WM, int WN, int MI, int NI, int KC, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_bwd_pair_k1_kernel(
+    DgradPtrs dp, WgradPtrs wp, int nW, int wgx, int wgy, int wgz, int dgx, int dgy, int mtiles, int B, int T, int Cin,
+    int Cout, int act, int tilesT, int tilesPerClip, int tilesPerSplit) {
+  constexpr int SM = cmax(dgrad_smem_floats<1, 1, WM, WN, MI, NI, KC, KG, false>(),
+                          wgrad_smem_floats<1, 1, 2, 2, 1, 1, 128, KG>());
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  int id = blockIdx.x;
+  if (id < nW) {
+    const int bx = id % wgx, by = (id / wgx) % wgy, bz = id / (wgx * wgy);
+    conv_wgrad_body<1, 1, 2, 2, 1, 1, 128, KG, true>(smem, wp, mtiles, B, T, Cin, T, Cout, act, tilesPerClip,
+                                                     tilesPerSplit, 1, bx, by, bz, wgz);
+  } else {
+    id -= nW;
+    const int bx = id % dgx, by = (id / dgx) % dgy, bz = id / (dgx * dgy);
+    conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KG, false>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
+  }
 }
 
 // column sums of g = dy*mask*act'(pre): partial[blockIdx.x][n]
@@ -798,7 +853,7 @@ inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, 
 // ("bf16x3") operands in the forward kernels (experimental, avdf_gemm_mode)
 static int g_gemm_mode = [] { const char* e = getenv("AVDF_GEMM_MODE"); return e ? atoi(e) : 0; }();
 // process-wide override used by the tuner: g_override[kind] = {a, b}, -1 = off
-static int g_override[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+static int g_override[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};   // [3] unused, [4] = backward pair
 
 inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, int stride = 0, int Kred = 0) {
   {
@@ -923,6 +978,9 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
 static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
                              int stride, int pad, int ldx, int ldw, int ldy, int act, hipStream_t st, long xbs = -1,
                              long wbs = 0, long ybs = -1) {
+  // K=1 is a plain GEMM over the B*T token rows: drop the clip structure (no halo between clips) so that short
+  // pyramid levels (T = 12..96) are not padded to one M-tile per clip
+  if (K == 1 && stride == 1 && pad == 0 && xbs < 0 && ybs < 0 && wbs == 0) { Tin = Tout = B * Tin; B = 1; }
   if (xbs < 0) xbs = (long)Tin * ldx;
   if (ybs < 0) ybs = (long)Tout * ldy;
   const TilePlan plan = pick_tile(B * nprob, Tout, Cout, false, K, stride, Cin);
@@ -1023,6 +1081,7 @@ extern "C" int avdf_conv1d_fwd_ex(const float* x, const float* w, const float* b
 
 static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin, int Cin, int Tout, int Cout, int K,
                                int stride, int act, hipStream_t st) {
+  if (K == 1 && stride == 1) { Tin = Tout = B * Tin; B = 1; }      // plain GEMM over the token rows (see conv1d_fwd_launch)
   const TilePlan plan = pick_tile(B * nprob, Tin, Cin, true, K, stride, Cout);
 #define LAUNCH_DG(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                                  \
   do {                                                                                                    \
@@ -1103,6 +1162,10 @@ extern "C" int64_t avdf_conv1d_bwd_weight_ws(int B, int Tout, int Cin, int Cout,
   for (int s_ = 0; s_ <= 2; ++s_) {
     const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, 1, s_);
     if (p.splits > splits) splits = p.splits;
+    if (K == 1) {                        // K=1 launches run on the flattened (1, B*T) problem
+      const WgradPlan q = wgrad_plan(1, B * Tout, Cin, Cout, K, 1, s_);
+      if (q.splits > splits) splits = q.splits;
+    }
   }
   const int64_t slab = (splits > 1) ? (int64_t)splits * Cout * Cin * K : 0;
   return slab + (int64_t)kColsumBlocks * Cout;
@@ -1150,6 +1213,7 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_weight: Tout inconsistent");
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws) && (!ypre || aligned16(ypre)), "conv1d_bwd_weight: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
+  if (K == 1 && stride == 1) { Tin = Tout = B * Tin; B = 1; }      // plain GEMM over the token rows
   const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, 1, stride);
   // accumulate != 0 (engine path): partial tiles and the bias column sums are added into dw / dbias with
   // float atomics -- one launch, no slabs; gradients then differ run-to-run in the last bits, like any
@@ -1204,13 +1268,87 @@ extern "C" int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, con
     g.mask[i] = mask ? mask[j] : nullptr; g.ypre[i] = ypre ? ypre[j] : nullptr; g.dbias[i] = dbias ? dbias[j] : nullptr;
     AVDF_REQUIRE(aligned16(g.dy[i]) && aligned16(g.x[i]) && aligned16(g.ypre[i]), "conv1d_bwd_weight_grouped: 16-byte alignment");
   }
+  if (K == 1 && stride == 1) { Tin = Tout = B * Tin; B = 1; }
   WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, n, stride);
   return conv1d_wgrad_launch(g, n, p, B, Tin, Cin, Tout, Cout, K, stride, act, accumulate, true, (hipStream_t)stream);
 }
 
+// K=1 / stride-1 layers (every Linear of the transformer blocks and heads): data gradient and weight gradient of
+// n <= 3 same-shape problems in ONE launch (conv_bwd_pair_k1_kernel).  Weight / bias gradients are ACCUMULATED into
+// dw[i] / dbias[i] with float atomics (the engine's flat-gradient path); dx[i] is overwritten.  g_pair_mode 0 turns
+// the fusion off (two launches, the reference point of tools/gemm_bench.py).
+static int g_pair_mode = [] { const char* e = getenv("AVDF_BWD_PAIR"); return e ? atoi(e) : 1; }();
+extern "C" int avdf_bwd_pair_mode(int mode) { g_pair_mode = mode; return AVDF_OK; }
+
+extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const float* const* w, const float* const* x,
+                                            const float* const* mask, const float* const* ypre, float* const* dx,
+                                            float* const* dw, float* const* dbias, int B, int T, int Cin, int Cout,
+                                            int act, void* stream) {
+  AVDF_REQUIRE(n >= 1 && n <= 3 && dy && w && x && dx && dw, "conv1d_bwd_pair: 1..3 problems, non-null tables");
+  AVDF_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0, "conv1d_bwd_pair: bad dims");
+  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_pair: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
+  DgradPtrs d;
+  WgradPtrs g;
+  for (int i = 0; i < 3; ++i) {
+    const int j = i < n ? i : 0;
+    AVDF_REQUIRE(dy[j] && w[j] && x[j] && dx[j] && dw[j], "conv1d_bwd_pair: null pointer (problem %d)", j);
+    d.dy[i] = dy[j]; d.w[i] = w[j]; d.dx[i] = dx[j];
+    g.dy[i] = dy[j]; g.x[i] = x[j]; g.out[i] = dw[j]; g.dbias[i] = dbias ? dbias[j] : nullptr;
+    d.mask[i] = g.mask[i] = mask ? mask[j] : nullptr;
+    d.ypre[i] = g.ypre[i] = ypre ? ypre[j] : nullptr;
+    AVDF_REQUIRE(aligned16(d.dy[i]) && aligned16(d.w[i]) && aligned16(g.x[i]) && aligned16(d.ypre[i]),
+                 "conv1d_bwd_pair: 16-byte alignment");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  T = B * T; B = 1;                                                  // plain GEMM over the token rows
+  WgradPlan p = wgrad_plan(B, T, Cin, Cout, 1, n, 1);
+  TilePlan plan = pick_tile(B * n, T, Cin, true, 1, 1, Cout);
+  {
+    // plans measured for the fused launch (table kind 4: a = dgrad tile, b = K-groups | wgrad token splits << 3)
+    int a = -1, b = -1;
+    if (g_override[4][0] >= 0) { a = g_override[4][0]; b = g_override[4][1]; }
+    else if (g_override[4][0] != -2) {
+      const TunedPlan* t = tuned_lookup(4, 1, 1, n * T, Cin, Cout);
+      if (t) { a = t->a; b = t->b; }
+    }
+    if (a >= 0 && a <= 4 && (b >> 3) >= 1) {
+      const int mk_[5] = {1, 2, 4, 4, 2};
+      int kg = b & 7;
+      if (kg != 1 && kg != 2 && kg != 4) kg = 1;
+      if (kg > mk_[a]) kg = mk_[a];
+      plan = TilePlan{a, kg, 0};
+      const int total = B * p.tilesPerClip;
+      int want = b >> 3;
+      if (want > total) want = total;
+      p.tilesPerSplit = cdiv(total, want);
+      p.splits = cdiv(total, p.tilesPerSplit);
+    }
+  }
+  if (!g_pair_mode || !p.small) {
+    int rc = conv1d_dgrad_launch(d, n, B, T, Cin, T, Cout, 1, 1, act, st);
+    if (rc) return rc;
+    return conv1d_wgrad_launch(g, n, p, B, T, Cin, T, Cout, 1, 1, act, 1, true, st);
+  }
+#define LAUNCH_PAIR(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                                          \
+  do {                                                                                                              \
+    constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                                       \
+    const int tilesT = cdiv(T, BM_);                                                                                \
+    const int dgx = B * tilesT, dgy = cdiv(Cin, BN_);                                                               \
+    const int wgx = p.mtiles * n, wgy = p.ctiles, wgz = p.splits;                                                   \
+    const int nW = wgx * wgy * wgz, nD = dgx * dgy * n;                                                             \
+    hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_>), dim3(nW + nD), dim3(256 * KG_), 0,  \
+                       st, d, g, nW, wgx, wgy, wgz, dgx, dgy, p.mtiles, B, T, Cin, Cout, act, tilesT,               \
+                       p.tilesPerClip, p.tilesPerSplit);                                                            \
+  } while (0)
+  AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, LAUNCH_PAIR)
+#undef LAUNCH_PAIR
+  AVDF_CHECK_LAUNCH("conv1d_bwd_pair");
+  return AVDF_OK;
+}
+
 // tuner hook (tools/autotune.py): kind 0 fwd / 1 dgrad: (tile, K-groups); 2 wgrad: (token splits, K-groups); a < 0 = off
 extern "C" int avdf_gemm_override(int kind, int a, int b) {
-  AVDF_REQUIRE(kind >= 0 && kind < 3, "gemm_override: kind in 0..2");
+  AVDF_REQUIRE(kind >= 0 && kind < 5 && kind != 3, "gemm_override: kind in {0, 1, 2, 4}");
   g_override[kind][0] = a;
   g_override[kind][1] = b;
   return AVDF_OK;

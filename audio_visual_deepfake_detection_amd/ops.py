@@ -183,6 +183,21 @@ class Conv1dFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         st = _stream()
+        mw, mb = ctx.main
+        if (K == 1 and stride == 1 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and mw is not None
+                and (not has_bias or mb is not None) and BWD_PAIR and not WGRAD_SIDE_STREAM):
+            # engine path: dgrad + wgrad (accumulated into the flat gradient buffer) of the layer in one launch
+            dx = torch.empty_like(x)
+            fl = 4.0 * B * Tout * Cout * Cin
+            _timed("conv_bwdpair_k1s1", fl, lambda: check(
+                lib.avdf_conv1d_bwd_pair_grouped(1, _ptr_table([dy]), _ptr_table([w]), _ptr_table([x]),
+                                                 _ptr_table([mask]) if mask is not None else None,
+                                                 _ptr_table([ypre]) if ypre is not None else None, _ptr_table([dx]),
+                                                 _ptr_table([mw.view(w.shape)]),
+                                                 _ptr_table([mb.view(Cout)]) if has_bias else None,
+                                                 B, Tin, Cin, Cout, act, st), "conv1d_bwd_pair"),
+                   ("pair", K, stride, B, Tin, Cin, Cout, 1))
+            return dx, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             fl = 2.0 * B * Tout * Cout * Cin * K
@@ -208,6 +223,7 @@ class Conv1dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+BWD_PAIR = True      # K=1 layers: data + weight gradient in one launch (avdf_conv1d_bwd_pair_grouped) on the engine path
 GEMM_MODE = 0        # forward conv GEMMs: 0 = exact fp32 MFMA, 1 = split-bf16 operands (bf16x3, ~5e-6 relative error)
 INFER_BF16X3 = True  # inference paths (model.eval(), InferStep, the frozen extractors) run their forward GEMMs in bf16x3
 
@@ -298,6 +314,17 @@ class Conv1dGroup3Fn(torch.autograd.Function):
         st = _stream()
         fl = 3 * 2.0 * B * T * Cout * Cin * K
         dxs = [None] * 3
+        mw, mb = ctx.main
+        acc = 1 if all(m is not None for m in mw) and (not has_bias or all(m is not None for m in mb)) else 0
+        if K == 1 and acc and all(ctx.needs_input_grad[0:3]) and BWD_PAIR and not WGRAD_SIDE_STREAM:
+            dxs = [torch.empty_like(x) for x in xs]
+            _timed("conv_bwdpair3_k1s1", 2 * fl, lambda: check(
+                lib.avdf_conv1d_bwd_pair_grouped(3, _ptr_table(dys), _ptr_table(ws_), _ptr_table(xs), None, None,
+                                                 _ptr_table(dxs), _ptr_table([m.view(ws_[0].shape) for m in mw]),
+                                                 _ptr_table([m.view(Cout) for m in mb]) if has_bias else None,
+                                                 B, T, Cin, Cout, ACT_NONE, st), "conv1d_bwd_pair"),
+                   ("pair", K, 1, B, T, Cin, Cout, 3))
+            return (*dxs, None, None, None, None, None, None)
         if any(ctx.needs_input_grad[0:3]):
             dxs = [torch.empty_like(x) for x in xs]
             _timed(_conv_tag("dgrad3", K, 1, 3 * B, T, Cin), fl, lambda: check(

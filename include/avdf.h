@@ -58,8 +58,19 @@ int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* c
                                    int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int act,
                                    int accumulate, void* stream);
 
-/* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..3, K-groups); 2 wgrad:
- * (token splits, K-groups)); a = -1 restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only. */
+/* K=1 / stride-1 layers: data gradient (dx[i] overwritten) AND weight / bias gradient (ACCUMULATED into dw[i] /
+ * dbias[i] with float atomics, as avdf_conv1d_bwd_weight_grouped with accumulate != 0) of n <= 3 same-shape problems
+ * in one launch.  Replaces the two autograd nodes of nn.Conv1d(k=1) / nn.Linear backward in the reference's blocks
+ * (libs/modeling/blocks.py:53-94 MaskedConv1D).  avdf_bwd_pair_mode(0) falls back to two launches.               */
+int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const float* const* w, const float* const* x,
+                                 const float* const* mask, const float* const* ypre, float* const* dx,
+                                 float* const* dw, float* const* dbias, int B, int T, int Cin, int Cout, int act,
+                                 void* stream);
+int avdf_bwd_pair_mode(int mode);
+
+/* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..4, K-groups + 8*double
+ * buffer); 2 wgrad: (token splits, K-groups); 4 backward pair: (dgrad tile, K-groups | wgrad splits << 3)); a = -1
+ * restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only.                                      */
 int avdf_gemm_override(int kind, int a, int b);
 
 /* avdf_conv1d_fwd_ex with explicit batch strides (floats): batch b reads x + b*xbs, multiplies by the weight matrix

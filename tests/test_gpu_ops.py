@@ -528,3 +528,68 @@ def test_conv1d_every_gemm_plan(ops, shape):
     finally:
         for k in range(3):
             check(lib.avdf_gemm_override(k, -1, -1), "override")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,T,Cin,Cout,act", [(1, 2, 200, 64, 136, 1), (3, 3, 192, 256, 256, 0), (1, 8, 96, 1024, 256, 0),
+                                                (2, 1, 12, 256, 1024, 2)])
+def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
+    """avdf_conv1d_bwd_pair_grouped (K=1 dgrad + accumulating wgrad in one launch) for every dgrad plan the tuner may
+    select, against the two separate entry points (dx bit-identical: same workgroup body) and against float64."""
+    import ctypes
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    st = torch.cuda.current_stream().cuda_stream
+    xs = [g32(rnd(B, T, Cin, seed=10 + i)) for i in range(n)]
+    ws_ = [g32(rnd(Cout, Cin, 1, seed=20 + i, scale=Cin ** -0.5)) for i in range(n)]
+    dys = [g32(rnd(B, T, Cout, seed=30 + i)) for i in range(n)]
+    ypres = [g32(rnd(B, T, Cout, seed=40 + i)) for i in range(n)]
+    mask = (torch.arange(T)[None, :] < torch.tensor([T - 3 * b for b in range(B)])[:, None]).float().to(dev()).contiguous()
+    masks = [mask] * n
+    # float64 reference: g = dy * mask * act'(ypre); dx = g @ W; dw = g^T x; db = colsum(g)
+    def gref(i):
+        g = dys[i].double() * mask.double()[..., None]
+        p = ypres[i].double()
+        if act == 1:
+            g = g * (p > 0)
+        elif act == 2:
+            g = g * (0.5 * (1 + torch.erf(p / 2 ** 0.5)) + p * torch.exp(-0.5 * p * p) / (2 * torch.pi) ** 0.5)
+        return g
+    base_dw = [g32(rnd(Cout, Cin, 1, seed=50 + i)) for i in range(n)]
+    base_db = [g32(rnd(Cout, seed=60 + i)) for i in range(n)]
+    # separate launches (the reference point)
+    dx_sep = [torch.empty(B, T, Cin, device=dev()) for _ in range(n)]
+    try:
+        check(lib.avdf_gemm_override(4, -2, -2), "override")      # the pair's own table rows off: plans come from kind 1 / 2
+        for tile in range(5):
+            for kg in (1, 2, 4):
+                if kg > (1, 2, 4, 4, 2)[tile]:
+                    continue
+                check(lib.avdf_gemm_override(1, tile, kg), "override")
+                check(lib.avdf_conv1d_bwd_data_grouped(n, tab(dys), tab(ws_), tab(masks), tab(ypres), tab(dx_sep), B, T, Cin, T, Cout,
+                                                       1, 1, act, st), "dgrad")
+                dx = [torch.full((B, T, Cin), float("nan"), device=dev()) for _ in range(n)]
+                dw = [b.clone() for b in base_dw]
+                db = [b.clone() for b in base_db]
+                check(lib.avdf_conv1d_bwd_pair_grouped(n, tab(dys), tab(ws_), tab(xs), tab(masks), tab(ypres), tab(dx), tab(dw), tab(db),
+                                                       B, T, Cin, Cout, act, st), "pair")
+                for i in range(n):
+                    g = gref(i)
+                    assert torch.equal(dx[i], dx_sep[i]), f"dx differs from the separate dgrad launch (tile {tile} kg {kg})"
+                    close(dx[i], (g @ ws_[i][:, :, 0].double()).cpu(), f"dx tile {tile} kg {kg}")
+                    close(dw[i][:, :, 0] - base_dw[i][:, :, 0],
+                          torch.einsum("btn,btc->nc", g, xs[i].double()).cpu(), f"dw tile {tile} kg {kg}", rtol=2e-4)
+                    close(db[i] - base_db[i], g.sum((0, 1)).cpu(), f"db tile {tile} kg {kg}", rtol=2e-4)
+        # fusion off: same entry, two launches
+        check(lib.avdf_gemm_override(1, -1, -1), "override")
+        check(lib.avdf_bwd_pair_mode(0), "mode")
+        dx = [torch.empty(B, T, Cin, device=dev()) for _ in range(n)]
+        dw = [torch.zeros(Cout, Cin, 1, device=dev()) for _ in range(n)]
+        check(lib.avdf_conv1d_bwd_pair_grouped(n, tab(dys), tab(ws_), tab(xs), tab(masks), tab(ypres), tab(dx), tab(dw), None,
+                                               B, T, Cin, Cout, act, st), "pair off")
+        for i in range(n):
+            close(dw[i][:, :, 0], torch.einsum("btn,btc->nc", gref(i), xs[i].double()).cpu(), "dw (pair off)", rtol=2e-4)
+    finally:
+        check(lib.avdf_bwd_pair_mode(1), "mode")
+        for k in (0, 1, 2, 4):
+            check(lib.avdf_gemm_override(k, -1, -1), "override")

@@ -1,13 +1,15 @@
 """Measure every GEMM plan for the conv shapes of one exp10 training step and write csrc/gemm_tuned.inc.
 
-    python tools/autotune.py [--batch 8] [--out audio_visual_deepfake_detection_amd/csrc/gemm_tuned.inc]
+    python tools/autotune.py [--batch 8 32] [--kinds fwd dgrad wgrad fwd3 pair] [--out gpurun_out/gemm_tuned.inc]
 
 1. runs one eager training step with ops.shape_log on -> the set of (kind, K, stride, B, T, Cin, Cout, nprob) shapes;
-2. for every shape times all (tile, K-groups) choices (fwd / dgrad) or (token splits, K-groups) (wgrad) through
+2. for every shape times all (tile, K-groups) choices (fwd / dgrad; fwd3 = the forward shapes again in split-bf16 mode),
+   (token splits, K-groups) (wgrad) or (dgrad tile, K-groups, wgrad splits) (pair: the K=1 one-launch backward) through
    avdf_gemm_override, `iters` launches captured in one hipGraph (L2-warm steady state, no host gaps);
-3. keeps a tuned entry only where it beats the heuristic plan by > 3 %, writes the table and a JSON report.
-Rebuild the library afterwards (python audio_visual_deepfake_detection_amd/csrc/build.py)."""
-import os, argparse, json, os, sys
+3. starts from the table in the tree, replaces every re-measured shape (an entry is kept only where it beats the baseline
+   plan by > 3 %), writes the merged table to --out and a JSON report.
+Copy --out over csrc/gemm_tuned.inc and rebuild (python audio_visual_deepfake_detection_amd/csrc/build.py)."""
+import argparse, json, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from audio_visual_deepfake_detection_amd import build_model, ops
@@ -47,12 +49,32 @@ def bench_shape(shape, iters):
     ys = [torch.randn(B, Tout, Cout, device=dev) for _ in range(n)]
     dws = [torch.zeros_like(w) for w in ws_]
     T = lambda ts: ops._ptr_table(ts)
+    tiles = [(t, kg) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t]]
+    if kind == "pair":
+        # (dgrad tile, K-groups) x (wgrad token splits); the baseline is the table / heuristic plan of the two halves
+        dxs = [torch.empty_like(x) for x in xs]
+        fn = lambda: check(lib.avdf_conv1d_bwd_pair_grouped(n, T(ys), T(ws_), T(xs), None, None, T(dxs), T(dws), None, B, Tin, Cin, Cout, 0,
+                                                            st()), "p")
+        check(lib.avdf_gemm_override(4, -2, -2), "o")      # ignore kind-4 rows: the halves' own plans
+        base = timeit(fn, iters)
+        best, best_us, res = None, base, {}
+        for t_, kg in tiles:
+            for sp in (1, 2, 4, 8, 16, 32, 64):
+                if sp > max(1, (B * Tin + 127) // 128):
+                    continue
+                check(lib.avdf_gemm_override(4, t_, kg | (sp << 3)), "o")
+                us = timeit(fn, iters)
+                res[f"{t_},{kg},{sp}"] = round(us, 2)
+                if us < best_us:
+                    best, best_us = (t_, kg | (sp << 3)), us
+        check(lib.avdf_gemm_override(4, -1, -1), "o")
+        return base, best, best_us, res
     if kind == "fwd":
         fn = lambda: check(lib.avdf_conv1d_fwd_grouped(n, T(xs), T(ws_), None, None, T(ys), None, B, Tin, Cin, Tout, Cout, K, s, 0, st()), "f")
-        cands = [(t, kg + 8 * db) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t] for db in (0, 1)]
+        cands = [(t_, kg + 8 * db) for t_, kg in tiles for db in (0, 1)]
     elif kind == "dgrad":
         fn = lambda: check(lib.avdf_conv1d_bwd_data_grouped(n, T(ys), T(ws_), None, None, T(xs), B, Tin, Cin, Tout, Cout, K, s, 0, st()), "d")
-        cands = [(t, kg + 8 * db) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t] for db in (0, 1)]
+        cands = [(t_, kg + 8 * db) for t_, kg in tiles for db in (0, 1)]
     else:
         wsb = torch.empty(8, device=dev)
         fn = lambda: check(lib.avdf_conv1d_bwd_weight_grouped(n, T(ys), T(xs), None, None, T(dws), None, wsb.data_ptr(), B, Tin, Cin, Tout,
@@ -73,15 +95,30 @@ def bench_shape(shape, iters):
     return base, best, best_us, res
 
 
+TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audio_visual_deepfake_detection_amd", "csrc",
+                     "gemm_tuned.inc")
+
+
+def load_table(path):
+    rows = {}
+    for l in open(path).read().splitlines():
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},(.*)", l)
+        if m:
+            v = [int(x) for x in m.groups()[:8]]
+            rows[tuple(v[:6])] = (v[6], v[7], m.group(9).strip())
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, nargs="+", default=[8], help="clips per GPU per step; several values -> one merged table")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                  "audio_visual_deepfake_detection_amd", "csrc", "gemm_tuned.inc"))
+    ap.add_argument("--kinds", nargs="+", default=["fwd", "dgrad", "wgrad", "fwd3", "pair"],
+                    help="fwd / dgrad / wgrad: exact-fp32 kernels; fwd3: forward shapes in split-bf16 mode (table kind 3); "
+                         "pair: K=1 dgrad+wgrad in one launch (table kind 4)")
+    ap.add_argument("--out", default="gpurun_out/gemm_tuned.inc",
+                    help="the table in the tree with every re-measured shape replaced; copy it over csrc/gemm_tuned.inc")
     ap.add_argument("--report", default="gpurun_out/autotune.json")
-    ap.add_argument("--bf16x3-fwd", action="store_true",
-                    help="measure only the forward shapes, in split-bf16 mode, and APPEND them as kind-3 rows to --out")
     args = ap.parse_args()
     log = {}
     for bsz in args.batch:
@@ -89,40 +126,46 @@ def main():
         print(f"batch {bsz}: {len(lg)} distinct GEMM shapes, {sum(lg.values())} launches per step", flush=True)
         for k, v in lg.items():
             log.setdefault(k, v)
-    rows, report, saved = [], [], 0.0
-    if args.bf16x3_fwd:
-        log = {k: v for k, v in log.items() if k[0] == "fwd"}
-        check(lib.avdf_gemm_mode(1), "mode")
+    table = load_table(TABLE)
+    report, saved = [], 0.0
+    work = []
     for shape, cnt in sorted(log.items(), key=lambda kv: kv[0]):
-        base, best, best_us, res = bench_shape(shape, args.iters)
+        if shape[0] in args.kinds:
+            work.append((shape, cnt, shape[0]))
+        if shape[0] == "fwd" and "fwd3" in args.kinds:
+            work.append((shape, cnt, "fwd3"))
+    for shape, cnt, mode in work:
         kind, K, s, B, Tin, Cin, Cout, n = shape
         Tout = (Tin + 2 * (K // 2) - K) // s + 1
+        check(lib.avdf_gemm_mode(1 if mode == "fwd3" else 0), "mode")
+        base, best, best_us, res = bench_shape(shape, args.iters)
         gain = (base - best_us) * cnt
-        print(f"{shape} x{cnt}: heuristic {base:7.1f} us, best {best} {best_us:7.1f} us  (saves {gain:6.1f} us/step)", flush=True)
-        report.append({"shape": list(shape), "launches": cnt, "heuristic_us": round(base, 2), "best": best, "best_us": round(best_us, 2), "all": res})
+        print(f"{mode} {shape[1:]} x{cnt}: baseline {base:7.1f} us, best {best} {best_us:7.1f} us  (saves {gain:6.1f} us/step)", flush=True)
+        report.append({"mode": mode, "shape": list(shape), "launches": cnt, "baseline_us": round(base, 2), "best": best,
+                       "best_us": round(best_us, 2), "all": res})
+        if mode == "fwd" or mode == "fwd3":
+            key = (3 if mode == "fwd3" else 0, K, s, B * n * Tout, Cout, Cin)
+        elif mode == "dgrad":
+            key = (1, K, s, B * n * Tin, Cin, Cout)
+        elif mode == "pair":
+            key = (4, K, s, B * n * Tin, Cin, Cout)
+        else:
+            key = (2, K, s, B * Tout, Cout * n, Cin)
+        table.pop(key, None)
         if best is not None and best_us < 0.97 * base:
             saved += gain
-            if kind == "fwd":
-                key = (3 if args.bf16x3_fwd else 0, K, s, B * n * Tout, Cout, Cin)
-            elif kind == "dgrad":
-                key = (1, K, s, B * n * Tin, Cin, Cout)
-            else:
-                key = (2, K, s, B * Tout, Cout * n, Cin)
-            rows.append("    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s x%d: %.1f -> %.1f us" % (*key, best[0], best[1], kind, cnt, base, best_us))
-    if args.bf16x3_fwd:
-        check(lib.avdf_gemm_mode(0), "mode")
-        cur = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "audio_visual_deepfake_detection_amd", "csrc", "gemm_tuned.inc")
-        keep = [l for l in open(cur).read().splitlines() if not l.startswith("{3,") and "(kind 3)" not in l]
-        with open(args.out, "w") as f:              # the table in the tree minus its old kind-3 rows, then the new ones
-            f.write("\n".join(keep) + "\n")
-            f.write("// forward shapes re-measured in split-bf16 mode (kind 3)\n" + "\n".join(rows) + ("\n" if rows else ""))
-    else:
-        with open(args.out, "w") as f:
-            f.write("// generated by tools/autotune.py (B=%s clips, exp10) -- {kind, K, stride, M, N, Kred, a, b},\n" % ",".join(map(str, args.batch)))
-            f.write("\n".join(rows) + ("\n" if rows else ""))
+            table[key] = (best[0], best[1], "// %s x%d: %.1f -> %.1f us" % (mode, cnt, base, best_us))
+    check(lib.avdf_gemm_mode(0), "mode")
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    with open(args.out, "w") as f:
+        f.write("// generated by tools/autotune.py (exp10 shapes) -- {kind, K, stride, M, N, Kred, a, b}; kinds: 0 fwd, 1 dgrad,\n"
+                "// 2 wgrad (splits, kg), 3 fwd in split-bf16 mode, 4 K=1 backward pair (dgrad tile, kg | splits << 3)\n")
+        for key in sorted(table):
+            a, b, note = table[key]
+            f.write("    {%d, %d, %d, %d, %d, %d, %d, %d},   %s\n" % (*key, a, b, note))
     os.makedirs(os.path.dirname(args.report) or ".", exist_ok=True)
     json.dump(report, open(args.report, "w"), indent=1)
-    print(f"wrote {len(rows)} tuned plans to {args.out}; predicted saving {saved/1e3:.2f} ms/step")
+    print(f"wrote {len(table)} tuned plans to {args.out}; predicted saving over the baselines {saved/1e3:.2f} ms/step")
 
 
 if __name__ == "__main__":
