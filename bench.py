@@ -58,13 +58,13 @@ def load_batch(eng, first_clip):
 def pmc_traffic(tag):
     """HBM bytes per launch of the kernel class `tag`, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
     gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, separate passes; tools/pmc_summary.py) -- or None."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
-        ent = json.load(open(path))["by_tag"].get(tag)
+        ent = json.load(open(path))["by_tag"].get(tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad").replace("bwdpair3", "bwdpair"))
         return None if ent is None else {"bytes_per_launch": ent["bytes_per_launch"], "fetch_bytes": ent["fetch_bytes"],
-                                         "write_bytes": ent["write_bytes"], "source": "profiles/r01_c_pmc_traffic.json"}
+                                         "write_bytes": ent["write_bytes"], "source": "profiles/r01_i_pmc_traffic.json"}
     except Exception:
         return None
 
@@ -72,12 +72,12 @@ def pmc_traffic(tag):
 def pmc_mfma_util(tag):
     """MFMA-pipe utilisation of the kernel class `tag` (SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x un-instrumented
     launch duration x 2.4 GHz); tools/pmc_mfma.py) from the committed PMC pass -- or None."""
-    path = os.path.join(ROOT, "profiles", "r01_g_pmc_mfma_util.json")
+    path = os.path.join(ROOT, "profiles", "r01_i_pmc_mfma_util.json")
     try:
         d = json.load(open(path))
-        tag = tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad")
+        tag = tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad").replace("bwdpair3", "bwdpair")
         return {"kernel": d["by_tag"][tag]["mfma_util"], "all_conv_kernels": d["all_conv_kernels"],
-                "source": "profiles/r01_g_pmc_mfma_util.json"}
+                "source": "profiles/r01_i_pmc_mfma_util.json"}
     except Exception:
         return None
 

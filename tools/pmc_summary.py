@@ -22,6 +22,8 @@ def load(d, counter):
 def tag_of(name):
     """bench.py roofline class of a rocprof kernel name: conv_{fwd,dgrad,wgrad}_k{K}s{S} (all tile variants folded;
     the grouped q/k/v launches run the same kernels and are folded in too)."""
+    if "conv_bwd_pair_k1_kernel" in name:
+        return "conv_bwdpair_k1s1"
     m = re.search(r"conv_(fwd|dgrad|wgrad)_kernel<(\d+), (\d+),", name)
     return None if not m else f"conv_{m.group(1)}_k{m.group(2)}s{m.group(3)}"
 
