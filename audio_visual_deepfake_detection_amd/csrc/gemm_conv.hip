@@ -119,7 +119,7 @@ constexpr int round8(int a) { return (a + 7) / 8 * 8; }
 template <int BM, int BN, int KG, int WN, int MI, int NI, class Emit>
 __device__ __forceinline__ void tile_epilogue(floatx16 (&acc)[MI * NI], float* smem, int kg, int wm, int wn, int li,
                                               int lh, int tid, Emit&& emit) {
-  constexpr int LDC = BN + 4, NT = 256 * KG;
+  constexpr int LDC = BN + 4, NT = 64 * (BM / (MI * 32)) * WN * KG;
   __syncthreads();
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -155,7 +155,7 @@ __device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0
 // forward
 // ------------------------------------------------------------------------------------------
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3 = false, bool DB = false>
-__global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
+__global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
     FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy,
     long xbs, long wbs, long ybs) {
   // xbs / wbs / ybs: batch strides of x, w, y in floats (default Tin*ldx, 0, Tout*ldy; attention heads use
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   float* __restrict__ ypre = pick3(ptrs.ypre, prob);
   // P = left zero-padding (K/2 for the "same" convs of the model, 0 for the wav2vec2 feature extractor);
   // ldx / ldw / ldy = row strides of x, w and y in floats (sub-matrix views: attention heads, weight slices)
-  static_assert(WM * WN == 4, "4 waves per K-group");
+  static_assert(WM * WN == 4 || WM * WN == 1, "4 waves (or, for the 32x32 tile, 1 wave) per K-group");
   static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
-  constexpr int NT = 256 * KG;
+  constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int RA = (BM - 1) * S + KS;
   constexpr int LDA = KC + 1;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256 * KG) void conv_fwd_kernel(
   __bf16* Bl = Bh + BSH;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int kg = wid >> 2, w4 = wid & 3;
+  const int kg = wid / WPG, w4 = wid % WPG;
   const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / tilesT, t0 = (blockIdx.x % tilesT) * BM;
@@ -420,9 +420,9 @@ __device__ __forceinline__ void conv_dgrad_body(
   const float* __restrict__ mask = pick3(ptrs.mask, prob);
   const float* __restrict__ ypre = pick3(ptrs.ypre, prob);
   float* __restrict__ dx = pick3(ptrs.dx, prob);
-  static_assert(WM * WN == 4, "4 waves per K-group");
+  static_assert(WM * WN == 4 || WM * WN == 1, "4 waves (or, for the 32x32 tile, 1 wave) per K-group");
   static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
-  constexpr int NT = 256 * KG;
+  constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RA = (BM + KS - 2) / S + 2;
   constexpr int LDA = KC + 1;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void conv_dgrad_body(
   float* Bs = smem + AS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int kg = wid >> 2, w4 = wid & 3;
+  const int kg = wid / WPG, w4 = wid % WPG;
   const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int b = bx / tilesT, tp0 = (bx % tilesT) * BM;
@@ -567,7 +567,7 @@ __device__ __forceinline__ void conv_dgrad_body(
 }
 
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false>
-__global__ __launch_bounds__(256 * KG) void conv_dgrad_kernel(
+__global__ __launch_bounds__(64 * WM * WN * KG) void conv_dgrad_kernel(
     DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
   __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB>()];
   conv_dgrad_body<KS, S, WM, WN, MI, NI, KC, KG, DB>(smem, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, blockIdx.x,
@@ -595,9 +595,9 @@ __device__ __forceinline__ void conv_wgrad_body(
   const float* __restrict__ ypre = pick3(ptrs.ypre, prob);
   float* __restrict__ out = pick3(ptrs.out, prob);
   float* __restrict__ dbias = pick3(ptrs.dbias, prob);
-  static_assert(WM * WN == 4, "4 waves per K-group");
+  static_assert(WM * WN == 4 || WM * WN == 1, "4 waves (or, for the 32x32 tile, 1 wave) per K-group");
   static_assert(KT % (2 * KG) == 0, "token tile must split evenly into pairs per group");
-  constexpr int NT = 256 * KG;
+  constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RX = (KT - 1) * S + KS;
   constexpr int Y4 = BM / 4, X4 = BN / 4;
@@ -610,7 +610,7 @@ __device__ __forceinline__ void conv_wgrad_body(
   float* Xs = smem + YS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int kg = wid >> 2, w4 = wid & 3;
+  const int kg = wid / WPG, w4 = wid % WPG;
   const int wm = w4 / WN, wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = (bx % mtiles) * BM, c0 = by * BN;
@@ -744,11 +744,13 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
 // K=1 data gradient AND weight gradient of the same layer(s) in ONE launch: workgroups [0, nW) run the wgrad body
 // (token-split, atomics into dw / dbias), workgroups [nW, nW + nD) the dgrad body.  Both read the same dy; issued as
 // one grid they fill the chip together instead of leaving two under-filled launches with a drain between them.
-template <int WM, int WN, int MI, int NI, int KC, int KG>
-__global__ __launch_bounds__(256 * KG) void conv_bwd_pair_k1_kernel(
+template <int WM, int WN, int MI, int NI, int KC, int KGD>
+__global__ __launch_bounds__(64 * WM * WN * KGD) void conv_bwd_pair_k1_kernel(
     DgradPtrs dp, WgradPtrs wp, int nW, int wgx, int wgy, int wgz, int dgx, int dgy, int mtiles, int B, int T, int Cin,
     int Cout, int act, int tilesT, int tilesPerClip, int tilesPerSplit) {
-  constexpr int SM = cmax(dgrad_smem_floats<1, 1, WM, WN, MI, NI, KC, KG, false>(),
+  constexpr int KG = WM * WN * KGD / 4;          // wgrad K-groups: same workgroup size (4 waves per wgrad K-group)
+  static_assert(KG == 1 || KG == 2 || KG == 4, "pair: workgroup of 256 / 512 / 1024 threads");
+  constexpr int SM = cmax(dgrad_smem_floats<1, 1, WM, WN, MI, NI, KC, KGD, false>(),
                           wgrad_smem_floats<1, 1, 2, 2, 1, 1, 128, KG>());
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int id = blockIdx.x;
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256 * KG) void conv_bwd_pair_k1_kernel(
   } else {
     id -= nW;
     const int bx = id % dgx, by = (id / dgx) % dgy, bz = id / (dgx * dgy);
-    conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KG, false>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
+    conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KGD, false>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
   }
 }
 
@@ -834,7 +836,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Output-tile and K-group choice for the forward / dgrad GEMMs: the largest tile that still yields
 // >= 2 workgroups per CU wins, otherwise the shape with the most workgroups; then as many K-groups
 // as needed to put ~1024+ wave-quads on the chip.
-// tile 0: 128x128  1: 64x128  2: 64x64  3: 32x128
+// tile 0: 128x128  1: 64x128  2: 64x64  3: 32x128  4: 256x64  5: 32x32 (K=1; table / tuner only)
 struct TilePlan { int tile, kg, db; };
 
 // ---- measured plans ----------------------------------------------------------------------------------------
@@ -858,10 +860,10 @@ static int g_override[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}
 inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, int stride = 0, int Kred = 0) {
   {
     const int kind = dgrad ? 1 : 0;
-    const int mk_[5] = {1, 2, 4, 4, 2};
+    const int mk_[6] = {1, 2, 4, 4, 2, 4};
     if (g_override[kind][0] >= 0) {
       TilePlan o{g_override[kind][0], g_override[kind][1] & 7, (g_override[kind][1] >> 3) & 1};
-      if (o.tile > 4) o.tile = 4;
+      if (o.tile > 5) o.tile = 5;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
       return o;
@@ -960,8 +962,14 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
 // the global-load latency of the next one at ~1 wave per SIMD.
 // tile 4 = 256x64 (4x1 waves of 64x64, the conv3d shape: 4 MFMAs per 4 LDS reads, long stages); only reached
 // through the tuned table / the tuner override
-#define AVDF_GEMM_DISPATCH(KS_, S_, KC0_, KC1_, KC2_, KC3_, KC4_, L)               \
+// tile 5 = 32x32 output tile, ONE wave per K-group and 4 / 8 / 16 K-groups (plan.kg = 1 / 2 / 4 codes K-groups / 4):
+// 4x the workgroups of the 64x64 tile for the layers whose tile count is below the CU count (K=1 only; for the k=3
+// convs W5_ = 2 aliases tile 2)
+#define AVDF_GEMM_DISPATCH(KS_, S_, KC0_, KC1_, KC2_, KC3_, KC4_, KC5_, W5_, L)    \
   switch (plan.tile * 8 + plan.kg) {                                               \
+    case 5 * 8 + 1: L(KS_, S_, KC5_, W5_, W5_, 1, 1, (W5_ == 1 ? 4 : 1)); break;   \
+    case 5 * 8 + 2: L(KS_, S_, KC5_, W5_, W5_, 1, 1, (W5_ == 1 ? 8 : 2)); break;   \
+    case 5 * 8 + 4: L(KS_, S_, KC5_, W5_, W5_, 1, 1, (W5_ == 1 ? 16 : 4)); break;  \
     case 4 * 8 + 1: L(KS_, S_, KC4_, 4, 1, 2, 2, 1); break;                        \
     case 4 * 8 + 2: L(KS_, S_, KC4_, 4, 1, 2, 2, 2); break;                        \
     case 0 * 8 + 1: L(KS_, S_, KC0_, 2, 2, 2, 2, 1); break;                        \
@@ -994,7 +1002,7 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     if constexpr ((KC_ / KG_) % 16 == 0) {                                                              \
       if (g_gemm_mode == 1) {                                                                           \
         hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
-                           dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
+                           dim3(64 * WM_ * WN_ * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
                            ldx, ldw, ldy, xbs, wbs, ybs);                                               \
         break;                                                                                          \
       }                                                                                                 \
@@ -1002,19 +1010,19 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     if constexpr (DBOK_) {                                                                              \
       if (plan.db) {                                                                                    \
         hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, false, true>), grid, \
-                           dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
+                           dim3(64 * WM_ * WN_ * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
                            ldx, ldw, ldy, xbs, wbs, ybs);                                               \
         break;                                                                                          \
       }                                                                                                 \
     }                                                                                                   \
-    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
+    hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(64 * WM_ * WN_ * KG_), \
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy, xbs, wbs, \
                        ybs);                                                                            \
   } while (0)
-  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, LAUNCH_FWD) }
-  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, LAUNCH_FWD) }
-  else if (K == 2 && stride == 2) { AVDF_GEMM_DISPATCH(2, 2, 64, 64, 64, 64, 32, LAUNCH_FWD) }
-  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, LAUNCH_FWD) }
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
+  else if (K == 2 && stride == 2) { AVDF_GEMM_DISPATCH(2, 2, 64, 64, 64, 64, 32, 64, 2, LAUNCH_FWD) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, 128, 1, LAUNCH_FWD) }
 #undef LAUNCH_FWD
   AVDF_CHECK_LAUNCH("conv1d_fwd");
   return AVDF_OK;
@@ -1093,16 +1101,16 @@ static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin,
     if constexpr (DBOK_) {                                                                                \
       if (plan.db) {                                                                                      \
         hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
-                           dim3(256 * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);           \
+                           dim3(64 * WM_ * WN_ * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);           \
         break;                                                                                            \
       }                                                                                                   \
     }                                                                                                     \
-    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(256 * KG_), \
+    hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_>), grid, dim3(64 * WM_ * WN_ * KG_), \
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);                                \
   } while (0)
-  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, LAUNCH_DG) }
-  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, LAUNCH_DG) }
-  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, LAUNCH_DG) }
+  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, 64, 2, LAUNCH_DG) }
+  else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, 64, 2, LAUNCH_DG) }
+  else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, 128, 1, LAUNCH_DG) }
 #undef LAUNCH_DG
   AVDF_CHECK_LAUNCH("conv1d_bwd_data");
   return AVDF_OK;
@@ -1311,8 +1319,8 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
       const TunedPlan* t = tuned_lookup(4, 1, 1, n * T, Cin, Cout);
       if (t) { a = t->a; b = t->b; }
     }
-    if (a >= 0 && a <= 4 && (b >> 3) >= 1) {
-      const int mk_[5] = {1, 2, 4, 4, 2};
+    if (a >= 0 && a <= 5 && (b >> 3) >= 1) {
+      const int mk_[6] = {1, 2, 4, 4, 2, 4};
       int kg = b & 7;
       if (kg != 1 && kg != 2 && kg != 4) kg = 1;
       if (kg > mk_[a]) kg = mk_[a];
@@ -1336,11 +1344,11 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
     const int dgx = B * tilesT, dgy = cdiv(Cin, BN_);                                                               \
     const int wgx = p.mtiles * n, wgy = p.ctiles, wgz = p.splits;                                                   \
     const int nW = wgx * wgy * wgz, nD = dgx * dgy * n;                                                             \
-    hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_>), dim3(nW + nD), dim3(256 * KG_), 0,  \
+    hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_>), dim3(nW + nD), dim3(64 * WM_ * WN_ * KG_), 0,  \
                        st, d, g, nW, wgx, wgy, wgz, dgx, dgy, p.mtiles, B, T, Cin, Cout, act, tilesT,               \
                        p.tilesPerClip, p.tilesPerSplit);                                                            \
   } while (0)
-  AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, LAUNCH_PAIR)
+  AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, 128, 1, LAUNCH_PAIR)
 #undef LAUNCH_PAIR
   AVDF_CHECK_LAUNCH("conv1d_bwd_pair");
   return AVDF_OK;

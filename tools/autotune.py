@@ -49,7 +49,7 @@ def bench_shape(shape, iters):
     ys = [torch.randn(B, Tout, Cout, device=dev) for _ in range(n)]
     dws = [torch.zeros_like(w) for w in ws_]
     T = lambda ts: ops._ptr_table(ts)
-    tiles = [(t, kg) for t in range(5) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2)[t]]
+    tiles = [(t, kg) for t in range(6) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2, 4)[t]]
     if kind == "pair":
         # (dgrad tile, K-groups) x (wgrad token splits); the baseline is the table / heuristic plan of the two halves
         dxs = [torch.empty_like(x) for x in xs]
