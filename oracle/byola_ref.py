@@ -1,9 +1,11 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the BYOL-A extraction path.
 
-PARITY UNPINNED: the reference's front-end is torchaudio.transforms.MelSpectrogram (torchaudio is not installed
-here and no fixture exists) and its weights file is absent; this oracle restates the call site's parameters
-(audio_feature/content_audio/extract_audio_feature_batch.py:42-60, config.yaml:4-10) on torch.stft and the network
-(byol_a/models.py:53-85) on plain torch ops.  It pins the HIP path against torch, not against torchaudio.
+NETWORK PINNED, FRONT-END UNPINNED: `byola_forward` (byol_a/models.py:53-85) is checked against the reference's own
+AudioNTT2020Task6 class on seeded weights (oracle/make_golden.py byola_net -> tests/golden/byola_net.npz; that file
+imports only torch).  The log-mel front-end is torchaudio.transforms.MelSpectrogram upstream (torchaudio is not
+installed here, no fixture exists) and the weights file is absent: `log_mel` restates the call site's parameters
+(audio_feature/content_audio/extract_audio_feature_batch.py:42-60, config.yaml:4-10) on torch.stft and pins the HIP
+front-end against torch, not against torchaudio.
 """
 import math
 
@@ -48,3 +50,28 @@ def byola_forward(sd, lms):
     x = x.reshape(B, T, C * D)
     x = F.relu(F.linear(x, sd["fc.0.weight"], sd["fc.0.bias"]))
     return F.relu(F.linear(x, sd["fc.3.weight"], sd["fc.3.bias"]))
+
+
+BYOLA_KEYS = [("features.0", 64, 1), ("features.4", 64, 64), ("features.8", 64, 64)]
+
+
+def seeded_state_dict(seed, n_mels=64, d=2048):
+    """Deterministic AudioNTT2020Task6 state dict (reference key names) from numpy's legacy RandomState: fixtures carry
+    the seed, not the weights.  BatchNorm statistics are non-trivial on purpose."""
+    rs = np.random.RandomState(seed)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
+    sd = {}
+    for (name, co, ci), bn in zip(BYOLA_KEYS, (1, 5, 9)):
+        sd[f"{name}.weight"] = f32(rs.randn(co, ci, 3, 3) * (2.0 / (ci * 9)) ** 0.5)
+        sd[f"{name}.bias"] = f32(rs.randn(co) * 0.1)
+        sd[f"features.{bn}.weight"] = f32(1.0 + 0.1 * rs.randn(co))
+        sd[f"features.{bn}.bias"] = f32(0.1 * rs.randn(co))
+        sd[f"features.{bn}.running_mean"] = f32(0.3 * rs.randn(co))
+        sd[f"features.{bn}.running_var"] = f32(rs.uniform(0.5, 1.5, co))
+        sd[f"features.{bn}.num_batches_tracked"] = torch.tensor(1, dtype=torch.long)
+    fin = 64 * (n_mels // 8)
+    sd["fc.0.weight"] = f32(rs.randn(d, fin) * (2.0 / fin) ** 0.5)
+    sd["fc.0.bias"] = f32(rs.randn(d) * 0.1)
+    sd["fc.3.weight"] = f32(rs.randn(d, d) * (2.0 / d) ** 0.5)
+    sd["fc.3.bias"] = f32(rs.randn(d) * 0.1)
+    return sd

@@ -486,6 +486,31 @@ SMALL = dict(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, h
 MID = dict(input_dim=192, max_seq_len=384, embd_dim=128, n_head=4, fpn_dim=128, head_dim=128)
 
 
+def case_byola_net():
+    """BYOL-A network: the reference's own AudioNTT2020Task6 (audio_feature/content_audio/byol_a/models.py:48-85, a file
+    that imports only torch -- loaded by path so that byol_a/common.py's torchaudio import is never reached) on seeded
+    weights and a seeded log-mel batch; asserts the oracle restatement against it and stores the reference output."""
+    import importlib.util
+    from oracle import byola_ref as BR
+    spec = importlib.util.spec_from_file_location("byol_a_models_ref", os.path.join(REF, "audio_feature", "content_audio", "byol_a", "models.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(mod)
+    wseed, xseed = 4242, 4243
+    net = mod.AudioNTT2020Task6(n_mels=64, d=2048).eval()
+    sd = BR.seeded_state_dict(wseed)
+    missing = net.load_state_dict(sd, strict=True)
+    lms = torch.from_numpy(np.random.RandomState(xseed).randn(2, 1, 64, 203).astype(np.float32))
+    with torch.no_grad():
+        ref = net(lms)
+        mine = BR.byola_forward(sd, lms)
+    err = float((ref - mine).abs().max() / ref.abs().max())
+    print(f"byola_net: reference out {tuple(ref.shape)}, oracle vs reference rel err {err:.2e}")
+    assert err < 1e-6 and ref.shape == (2, 25, 2048)
+    np.savez_compressed(os.path.join(GOLD, "byola_net.npz"), wseed=wseed, xseed=xseed, lms_shape=np.array(lms.shape),
+                        out=ref.numpy())
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -496,6 +521,7 @@ def main():
     case_datasets()
     case_metrics()
     case_lr_schedules()
+    case_byola_net()
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
     case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
     case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)
@@ -539,6 +565,9 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()
         case_nms_modes()
+    elif len(sys.argv) > 1 and sys.argv[1] == "byola_net":
+        os.makedirs(GOLD, exist_ok=True)
+        case_byola_net()
     elif len(sys.argv) > 1 and sys.argv[1] == "lr":
         os.makedirs(GOLD, exist_ok=True)
         import_reference()

@@ -30,3 +30,23 @@ def test_emotion2vec_restatement_length_rule_and_alibi_slopes():
     assert y.shape == (1, (4000 - 400) // 320 + 1, 768)
     s = R.slopes(12)
     assert len(s) == 12 and abs(s[0] - 2 ** -1) < 1e-12 and abs(s[7] - 2 ** -8) < 1e-12 and abs(s[8] - 2 ** -0.5) < 1e-12
+
+
+def test_byola_oracle_matches_reference_network(golden_dir):
+    """oracle/byola_ref.byola_forward == the reference's AudioNTT2020Task6 (byol_a/models.py:48-85) on the seeded weights
+    and log-mel batch of tests/golden/byola_net.npz (written by oracle/make_golden.py byola_net from the real class)."""
+    import os
+    import numpy as np
+    from oracle import byola_ref as BR
+    from audio_visual_deepfake_detection_amd.extractors import AudioNTT2020Task6
+    g = np.load(os.path.join(golden_dir, "byola_net.npz"))
+    sd = BR.seeded_state_dict(int(g["wseed"]))
+    lms = torch.from_numpy(np.random.RandomState(int(g["xseed"])).randn(*g["lms_shape"]).astype(np.float32))
+    out = BR.byola_forward(sd, lms)
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6
+    # the host module takes the reference checkpoint's keys as they are
+    m = AudioNTT2020Task6(64, 2048)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)

@@ -1,5 +1,6 @@
 """BYOL-A extraction path on a real MI355X vs the torch CPU restatement (oracle/byola_ref.py).
-PARITY UNPINNED upstream (no torchaudio / checkpoint in the reference tree): this pins HIP == torch."""
+The network is pinned to the reference's own class (tests/golden/byola_net.npz); the log-mel front-end is PARITY UNPINNED
+upstream (no torchaudio in the reference tree or this image): for it this pins HIP == torch."""
 import numpy as np
 import pytest
 import torch
@@ -33,6 +34,23 @@ def test_log_mel_front_end(n):
     err = float((got - ref).abs().max())
     print(f"log-mel n={n}: max abs err {err:.3e}")
     assert err < 1e-3
+
+
+def test_byola_network_matches_reference_golden(golden_dir):
+    """HIP BYOL-A network == the reference's AudioNTT2020Task6 output stored in tests/golden/byola_net.npz."""
+    import os
+    from audio_visual_deepfake_detection_amd.extractors import AudioNTT2020Task6
+    from oracle import byola_ref as R
+    g = np.load(os.path.join(golden_dir, "byola_net.npz"))
+    m = AudioNTT2020Task6(64, 2048)
+    m.load_state_dict(R.seeded_state_dict(int(g["wseed"])), strict=True)
+    lms = torch.from_numpy(np.random.RandomState(int(g["xseed"])).randn(*g["lms_shape"]).astype(np.float32))
+    got = m.eval().to("cuda:0")(lms.to("cuda:0")).cpu()
+    ref = torch.from_numpy(g["out"])
+    assert got.shape == ref.shape
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    print(f"BYOL-A net vs reference golden: rel err {rel:.3e}")
+    assert rel < 1e-4
 
 
 def test_byola_network_and_pipeline():
