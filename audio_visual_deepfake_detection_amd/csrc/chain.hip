@@ -114,6 +114,7 @@ struct ChainBwdArgs {
   const float* dy[3]; const float* u[3]; const float* sb[3]; const float* x[3]; const float* sa[3];
   const float* ga[3]; const float* ba[3]; const float* w[3]; const float* gb[3];
   float* dx[3];
+  const float* dres[3];   // optional: gradient arriving at the same input through the residual path, added into dx
 };
 
 // ws row of a workgroup: [3 branches][7*C]: dgamma_a, dbeta_a, dw (c*3+k order, 3C), dgamma_b, dbeta_b
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(64 * NW) void chain_bwd_kernel(ChainBwdArgs a, cons
 #pragma unroll
       for (int i = 0; i < NR2; ++i) {
         const int t = ti0 + wid + i * NW;
-        if (t < Tin && act) st4(a.dx[br] + ((size_t)b * Tin + t) * C + c, dxacc[i]);
+        if (t < Tin && act) {
+          const size_t o = ((size_t)b * Tin + t) * C + c;
+          st4(a.dx[br] + o, a.dres[br] ? add4(dxacc[i], ld4(a.dres[br] + o)) : dxacc[i]);
+        }
         dxacc[i] = f4(0.f);
       }
     }
@@ -343,6 +347,17 @@ extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, con
                               const float* const* beta_a, const float* const* w, const float* const* gamma_b,
                               const float* mask, float* const* dx, int store_mask, float* ws, int B, int Tin, int Tout,
                               int C, int stride, void* stream) {
+  return avdf_chain_bwd_res(dy, u, stats_b, x, stats_a, gamma_a, beta_a, w, gamma_b, mask, dx, nullptr, store_mask, ws, B, Tin,
+                            Tout, C, stride, stream);
+}
+
+// dres[i] (table or entries may be NULL): [B,Tin,C] gradient that reaches the input closed by branch i through another
+// path (the block's residual connection); dx[i] = LN_a backward sum + dres[i], saving autograd's separate add kernel.
+extern "C" int avdf_chain_bwd_res(const float* const* dy, const float* const* u, const float* const* stats_b,
+                                  const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                                  const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                                  const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
+                                  int B, int Tin, int Tout, int C, int stride, void* stream) {
   AVDF_REQUIRE(dy && u && stats_b && x && stats_a && gamma_a && beta_a && w && gamma_b && dx && ws, "chain_bwd: null table");
   AVDF_REQUIRE(B > 0 && Tin > 0 && C > 0 && C % 4 == 0 && C <= 256, "chain_bwd: C must be a multiple of 4, <= 256 (%d)", C);
   AVDF_REQUIRE(stride == 1 || stride == 2, "chain_bwd: stride must be 1 or 2");
@@ -357,6 +372,8 @@ extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, con
                  "chain_bwd: 16-byte alignment");
     a.dy[i] = dy[i]; a.u[i] = u[i]; a.sb[i] = stats_b[i]; a.x[i] = x[i]; a.sa[i] = stats_a[i];
     a.ga[i] = gamma_a[i]; a.ba[i] = beta_a[i]; a.w[i] = w[i]; a.gb[i] = gamma_b[i]; a.dx[i] = dx[i];
+    a.dres[i] = dres ? dres[i] : nullptr;
+    AVDF_REQUIRE(aligned16(a.dres[i]) && (!a.dres[i] || ((store_mask >> i) & 1)), "chain_bwd: dres must be 16-byte aligned and belong to a closing branch");
   }
   hipStream_t st = (hipStream_t)stream;
   const int tiles = cdiv(Tin, kTileB);

@@ -184,14 +184,16 @@ class _MHCABase(nn.Module):
                 and self.query_norm.eps == lns[0].eps and x_q.shape[1] % self.n_kv_stride == 0):
             out_mask = downsample_mask(masks[0], self.n_kv_stride)
             norms = (self.query_norm, self.key_norm, self.value_norm)
-            yq, yk, yv = ops.qkv_chain(
+            pt = torch.is_grad_enabled() and x_q.requires_grad
+            ys = ops.qkv_chain(
                 xs, [(ln.weight, ln.bias) for ln in lns],
                 [self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight],
-                [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps)
-            q, k, v = ops.conv1d_group3((yq, yk, yv), (self.query.weight, self.key.weight, self.value.weight),
+                [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps, passthrough=pt)
+            q, k, v = ops.conv1d_group3(ys[:3], (self.query.weight, self.key.weight, self.value.weight),
                                         (self.query.bias, self.key.bias, self.value.bias))
-            return self._core(q, k, v, out_mask, out_mask)
-        return self._attend(lns[0](x_q), masks[0], lns[1](x_k), masks[1], lns[2](x_v), masks[2])
+            # ys[3] (training): x_q handed back by the chain op for the caller's residual connection
+            return (*self._core(q, k, v, out_mask, out_mask), ys[3] if pt else x_q)
+        return (*self._attend(lns[0](x_q), masks[0], lns[1](x_k), masks[1], lns[2](x_v), masks[2]), x_q)
 
     def _core(self, q, k, v, qx_mask, kv_mask):
         if self.window_size > 1:
@@ -328,8 +330,8 @@ class TransformerBlock(_BlockBase):
 
     def forward(self, x, mask, pos_embd=None):
         assert pos_embd is None
-        out, out_mask = self.attn.attend_prenorm((x, x, x), (self.ln1, self.ln1, self.ln1), (mask, mask, mask))
-        return self._residual_mlp(x, out, out_mask), out_mask
+        out, out_mask, x_res = self.attn.attend_prenorm((x, x, x), (self.ln1, self.ln1, self.ln1), (mask, mask, mask))
+        return self._residual_mlp(x_res, out, out_mask), out_mask
 
 
 class MutilModelTransformerBlock(_BlockBase):
@@ -355,8 +357,9 @@ class MutilModelTransformerBlock(_BlockBase):
 
     def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None, pos_embd=None):
         assert pos_embd is None
-        out, out_mask = self.attn.attend_prenorm((x_q, x_k, x_v), (self.lnq, self.lnk, self.lnv), (mask_q, mask_k, mask_v))
-        return self._residual_mlp(x_q, out, out_mask), out_mask
+        out, out_mask, x_res = self.attn.attend_prenorm((x_q, x_k, x_v), (self.lnq, self.lnk, self.lnv),
+                                                        (mask_q, mask_k, mask_v))
+        return self._residual_mlp(x_res, out, out_mask), out_mask
 
 
 class ConvBlock(nn.Module):

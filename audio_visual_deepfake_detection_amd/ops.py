@@ -517,7 +517,7 @@ class QkvChainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xk, xv, gaq, baq, gak, bak, gav, bav, wq, wk, wv, gbq, bbq, gbk, bbk, gbv, bbv, mask, stride,
-                eps):
+                eps, passthrough=False):
         xs = [_c(xq), _c(xk), _c(xv)]
         ga, ba = [gaq, gak, gav], [baq, bak, bav]
         ws_, gb, bb = [wq, wk, wv], [gbq, gbk, gbv], [bbq, bbk, bbv]
@@ -542,10 +542,15 @@ class QkvChainFn(torch.autograd.Function):
         ctx.save_for_backward(*xs, *ga, *ba, *ws_, *gb, mask, *u, sa, sb)
         ctx.cfg = (B, Tin, Tout, C, stride)
         ctx.x_same = [xs[i + 1].data_ptr() == xs[i].data_ptr() for i in range(2)]
+        ctx.passthrough = bool(passthrough)
+        if ctx.passthrough:
+            # 4th output = x_q itself: the caller uses it for the block's residual connection, so x_q has ONE consumer
+            # in the autograd graph and the residual gradient arrives here (added into dx by the backward kernel)
+            return (*y, xq)
         return tuple(y)
 
     @staticmethod
-    def backward(ctx, dyq, dyk, dyv):
+    def backward(ctx, dyq, dyk, dyv, dres=None):
         sv = ctx.saved_tensors
         xs, ga, ba, ws_, gb = list(sv[0:3]), list(sv[3:6]), list(sv[6:9]), list(sv[9:12]), list(sv[12:15])
         mask, u, sa, sb = sv[15], list(sv[16:19]), sv[19], sv[20]
@@ -558,10 +563,14 @@ class QkvChainFn(torch.autograd.Function):
         dx = [torch.empty((B, Tin, C), dtype=torch.float32, device=dev) if st else None for st in store]
         store_mask = sum(1 << i for i, st in enumerate(store) if st)
         wsb = _ws(lib.avdf_chain_bwd_ws(B, Tin, C), xs[0])
-        check(lib.avdf_chain_bwd(_ptr_table(dys), _ptr_table(u), _ptr_table([sb[0], sb[1], sb[2]]), _ptr_table(xs),
-                                 _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_),
-                                 _ptr_table(gb), _p(mask), _ptr_table(dx), store_mask, _p(wsb), B, Tin, Tout, C, stride,
-                                 _stream()), "chain_bwd")
+        res = [None, None, None]
+        if dres is not None:
+            # the branch that closes x_q's input group stores dx for it
+            res[2 if (ctx.x_same[0] and ctx.x_same[1]) else (1 if ctx.x_same[0] else 0)] = dres.contiguous()
+        check(lib.avdf_chain_bwd_res(_ptr_table(dys), _ptr_table(u), _ptr_table([sb[0], sb[1], sb[2]]), _ptr_table(xs),
+                                     _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_),
+                                     _ptr_table(gb), _p(mask), _ptr_table(dx), _ptr_table(res), store_mask, _p(wsb), B, Tin,
+                                     Tout, C, stride, _stream()), "chain_bwd")
         # parameter gradients: one segmented reduction over the workgroups' rows; sources of a parameter shared by
         # several branches are summed there
         mains = ctx.main
@@ -595,14 +604,16 @@ class QkvChainFn(torch.autograd.Function):
                                        offs, 1 if acc else 0, _stream()), "reduce_segments")
         g = grads
         return (dx[0], dx[1], dx[2], g[0][0], g[1][0], g[0][1], g[1][1], g[0][2], g[1][2], g[2][0], g[2][1], g[2][2],
-                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None)
+                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None, None)
 
 
-def qkv_chain(xs, ln_a, dw, ln_b, mask_out, stride, eps=1e-5):
-    """xs: 3 inputs [B,T,C]; ln_a / ln_b: 3 (gamma, beta) pairs; dw: 3 depthwise weights [C,1,3] -> 3 outputs."""
+def qkv_chain(xs, ln_a, dw, ln_b, mask_out, stride, eps=1e-5, passthrough=False):
+    """xs: 3 inputs [B,T,C]; ln_a / ln_b: 3 (gamma, beta) pairs; dw: 3 depthwise weights [C,1,3] -> 3 outputs
+    (+ xs[0] handed back as a 4th output when `passthrough`: use THAT tensor for the residual connection and the
+    gradient of the residual path is summed inside the chain's backward kernel instead of by a separate add)."""
     return QkvChainFn.apply(xs[0], xs[1], xs[2], ln_a[0][0], ln_a[0][1], ln_a[1][0], ln_a[1][1], ln_a[2][0], ln_a[2][1],
                             dw[0], dw[1], dw[2], ln_b[0][0], ln_b[0][1], ln_b[1][0], ln_b[1][1], ln_b[2][0], ln_b[2][1],
-                            mask_out, stride, eps)
+                            mask_out, stride, eps, passthrough)
 
 
 # --------------------------------------------------------------------------------------------

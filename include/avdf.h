@@ -330,6 +330,14 @@ int avdf_chain_bwd(const float* const* dy, const float* const* u, const float* c
                    const float* const* beta_a, const float* const* w, const float* const* gamma_b,
                    const float* mask, float* const* dx, int store_mask, float* ws, int B, int Tin, int Tout,
                    int C, int stride, void* stream);
+/* avdf_chain_bwd with dres[i] (table or entries may be NULL): a [B,Tin,C] gradient reaching the input closed by branch i
+ * through the block's residual connection (blocks.py:1311 `out = pool_skip(x) * mask + drop_path(out)`); dx[i] gets the
+ * sum, which replaces autograd's separate accumulation kernel.                                                   */
+int avdf_chain_bwd_res(const float* const* dy, const float* const* u, const float* const* stats_b,
+                       const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                       const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                       const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
+                       int B, int Tin, int Tout, int C, int stride, void* stream);
 /* dst[s][i] (+)= sum over rows r < nrow and sources j < nsrc[s] of ws[r*row_stride + src_off[s*3+j] + i],
  * i < len[s]; up to 16 segments per launch (host arrays).                                                   */
 int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,

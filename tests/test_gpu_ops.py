@@ -367,7 +367,10 @@ def test_adamw_ema_kernel(ops):
 # fused LN -> depthwise k3 -> LN chains of q / k / v
 @pytest.mark.parametrize("B,T,C,stride,share", [(2, 96, 256, 1, "all"), (3, 70, 64, 1, "kv"), (2, 64, 32, 2, "none"),
                                                 (8, 768, 256, 1, "all"), (2, 130, 256, 2, "kv"), (1, 33, 8, 1, "all")])
-def test_qkv_chain_matches_torch(ops, B, T, C, stride, share):
+@pytest.mark.parametrize("passthrough", [False, True])
+def test_qkv_chain_matches_torch(ops, B, T, C, stride, share, passthrough):
+    """passthrough: the op also hands x_q back (4th output) for the block's residual connection; its gradient must be
+    summed into dx by the backward kernel (the reference graph simply uses x_q twice)."""
     if stride == 2 and T % 2:
         T += 1
     Tout = (T - 1) // stride + 1
@@ -397,7 +400,8 @@ def test_qkv_chain_matches_torch(ops, B, T, C, stride, share):
         z = F.layer_norm(x, (C,), ga.view(-1), ba.view(-1), eps)
         u = F.conv1d(z.transpose(1, 2), w, None, stride, 1, groups=C).transpose(1, 2) * mask[..., None]
         ref_y.append(F.layer_norm(u, (C,), gb.view(-1), bb.view(-1), eps))
-    sum((y * d).sum() for y, d in zip(ref_y, dys)).backward()
+    dres = rnd(B, T, C, seed=70)
+    (sum((y * d).sum() for y, d in zip(ref_y, dys)) + ((leaf(xs[0]) * dres).sum() if passthrough else 0.0)).backward()
 
     dmap = {}
     def dleaf(t):
@@ -405,10 +409,15 @@ def test_qkv_chain_matches_torch(ops, B, T, C, stride, share):
             dmap[id(t)] = g32(t, True)
         return dmap[id(t)]
     got = ops.qkv_chain([dleaf(x) for x in xs], [(dleaf(a), dleaf(b)) for a, b in la], [dleaf(w) for w in dw],
-                        [(dleaf(a), dleaf(b)) for a, b in lb], g32(mask), stride, eps)
+                        [(dleaf(a), dleaf(b)) for a, b in lb], g32(mask), stride, eps, passthrough=passthrough)
+    assert len(got) == (4 if passthrough else 3)
     for i in range(3):
         close(got[i], ref_y[i], f"chain y[{i}]")
-    sum((y * g32(d)).sum() for y, d in zip(got, dys)).backward()
+    loss = sum((y * g32(d)).sum() for y, d in zip(got[:3], dys))
+    if passthrough:
+        assert got[3].data_ptr() == dleaf(xs[0]).data_ptr()
+        loss = loss + (got[3] * g32(dres)).sum()
+    loss.backward()
     for key, t64 in uniq.items():
         close(dmap[key].grad, t64.grad, f"chain grad of tensor shape {tuple(t64.shape)}", rtol=5e-5)
 
