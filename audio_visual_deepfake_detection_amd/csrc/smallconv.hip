@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int kMaxN = 4;
-constexpr int kPartialBlocks = 64;
+constexpr int kPartialBlocks = 256;   // row-strided workgroups of the weight-gradient pass (one partial slab each)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void smallconv_dx_kernel(const float* __restri
   }
 }
 
-// partial[blockIdx.x][n][c][k]
+// partial[blockIdx.x][n][c][k]; one pass over the rows for all N outputs (x is read once per tap, not once per output)
 template <int KS>
 __global__ __launch_bounds__(256) void smallconv_dw_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                            float* __restrict__ partial, int B, int T, int Cin, int N) {
@@ -128,36 +128,46 @@ __global__ __launch_bounds__(256) void smallconv_dw_kernel(const float* __restri
   __shared__ float red[4][64 * 4 * KS];
   const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const long M = (long)B * T;
-  for (int n = 0; n < N; ++n) {
-    for (int cb = 0; cb < Cin; cb += 256) {
-      const int c = cb + cg * 4;
-      float4 a[KS];
+  for (int cb = 0; cb < Cin; cb += 256) {
+    const int c = cb + cg * 4;
+    float4 a[kMaxN][KS];
 #pragma unroll
-      for (int k = 0; k < KS; ++k) a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < Cin) {
-        for (long r = (long)blockIdx.x * 4 + rg; r < M; r += (long)gridDim.x * 4) {
-          const float gg = g[r * N + n];
-          const int t = (int)(r % T);
+    for (int n = 0; n < kMaxN; ++n)
 #pragma unroll
-          for (int k = 0; k < KS; ++k) {
-            const int ti = t + k - P;
-            if (ti >= 0 && ti < T) {
-              const float4 xv = ld4(x + (r + (k - P)) * Cin + c);
-              a[k].x += gg * xv.x; a[k].y += gg * xv.y; a[k].z += gg * xv.z; a[k].w += gg * xv.w;
+      for (int k = 0; k < KS; ++k) a[n][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < Cin) {
+      for (long r = (long)blockIdx.x * 4 + rg; r < M; r += (long)gridDim.x * 4) {
+        float gg[kMaxN];
+#pragma unroll
+        for (int n = 0; n < kMaxN; ++n) gg[n] = n < N ? g[r * N + n] : 0.f;
+        const int t = (int)(r % T);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int ti = t + k - P;
+          if (ti >= 0 && ti < T) {
+            const float4 xv = ld4(x + (r + (k - P)) * Cin + c);
+#pragma unroll
+            for (int n = 0; n < kMaxN; ++n) {
+              a[n][k].x += gg[n] * xv.x; a[n][k].y += gg[n] * xv.y; a[n][k].z += gg[n] * xv.z; a[n][k].w += gg[n] * xv.w;
             }
           }
         }
       }
-      float* d = &red[rg][cg * 4 * KS];
+    }
 #pragma unroll
-      for (int k = 0; k < KS; ++k) { d[0 * KS + k] = a[k].x; d[1 * KS + k] = a[k].y; d[2 * KS + k] = a[k].z; d[3 * KS + k] = a[k].w; }
-      __syncthreads();
-      for (int e = threadIdx.x; e < 256 * KS; e += 256) {
-        const int idx = cb * KS + e;
-        if (idx < Cin * KS)
-          partial[((size_t)blockIdx.x * N + n) * Cin * KS + idx] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    for (int n = 0; n < kMaxN; ++n) {
+      if (n < N) {
+        float* d = &red[rg][cg * 4 * KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) { d[0 * KS + k] = a[n][k].x; d[1 * KS + k] = a[n][k].y; d[2 * KS + k] = a[n][k].z; d[3 * KS + k] = a[n][k].w; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 256 * KS; e += 256) {
+          const int idx = cb * KS + e;
+          if (idx < Cin * KS)
+            partial[((size_t)blockIdx.x * N + n) * Cin * KS + idx] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
 }
