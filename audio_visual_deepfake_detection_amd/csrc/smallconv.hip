@@ -53,15 +53,15 @@ __global__ __launch_bounds__(256) void smallconv_fwd_kernel(
 }
 
 // g[b,t,n] = d(loss)/d(pre-mask conv output); also per-call sums for dbias / dscale (single block)
-__global__ __launch_bounds__(256) void smallconv_dpre_kernel(
+__global__ __launch_bounds__(1024) void smallconv_dpre_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ mask,
     const float* __restrict__ scale, float* __restrict__ g, float* __restrict__ dbias, float* __restrict__ dscale,
     long M, int N, int accumulate) {
-  __shared__ float red[256];
+  __shared__ float red[1024];
   float sb[kMaxN] = {0.f, 0.f, 0.f, 0.f};
   float ss = 0.f;
   const float sc = scale ? scale[0] : 1.f;
-  for (long r = threadIdx.x; r < M; r += 256) {
+  for (long r = threadIdx.x; r < M; r += 1024) {
     const float m = mask ? mask[r] : 1.f;
     for (int n = 0; n < N; ++n) {
       float d = dy[r * N + n];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void smallconv_dpre_kernel(
   for (int n = 0; n <= N; ++n) {
     red[threadIdx.x] = n < N ? sb[n < kMaxN ? n : 0] : ss;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
       if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
       __syncthreads();
     }
@@ -203,7 +203,7 @@ extern "C" int avdf_smallconv_bwd(const float* dy, const float* x, const float* 
   hipStream_t st = (hipStream_t)stream;
   float* g = ws;
   float* partial = ws + (size_t)B * T * Cout;
-  hipLaunchKernelGGL(smallconv_dpre_kernel, dim3(1), dim3(256), 0, st, dy, y, mask, scale, g, dbias, dscale, (long)B * T, Cout, accumulate);
+  hipLaunchKernelGGL(smallconv_dpre_kernel, dim3(1), dim3(1024), 0, st, dy, y, mask, scale, g, dbias, dscale, (long)B * T, Cout, accumulate);
   AVDF_CHECK_LAUNCH("smallconv_dpre");
   const dim3 grid((unsigned)(((long)B * T + 3) / 4));
   if (dx) {
