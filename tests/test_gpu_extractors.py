@@ -217,3 +217,29 @@ def test_video_features_chunking_and_tail_trim():
     err = float((got_full - ref).abs().max() / ref.abs().max())
     print(f"video_features: rel err {err:.2e}")
     assert err < 1e-4
+
+
+def test_extract_clip_batch_streams_equal_sequential():
+    """The two-stream overlap of the audio and video encoders (extractors.extract_clip_batch) changes no value."""
+    from audio_visual_deepfake_detection_amd.extractors import (LogMelFrontEnd, AudioNTT2020Task6, Emotion2Vec, C3DVideoEncoder,
+                                                                 extract_clip_batch)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    fe, byola = LogMelFrontEnd().to(dev), AudioNTT2020Task6().to(dev).eval()
+    e2v, c3d = Emotion2Vec(depth=2, prenet_depth=1).to(dev), C3DVideoEncoder().to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, T = 3, 24
+    pcm = torch.rand((B, 16000), generator=g, device=dev) - 0.5
+    frames = torch.randint(0, 256, (B, T, 64, 64, 3), generator=g, device=dev, dtype=torch.uint8)
+    mk = lambda: [(torch.zeros(T, 256, device=dev), torch.zeros(12, 2048, device=dev), torch.zeros(49, 768, device=dev))
+                  for _ in range(B)]
+    seq, par = mk(), mk()
+    extract_clip_batch(frames, pcm, c3d, byola, fe, e2v, seq, None)
+    torch.cuda.synchronize()
+    for _ in range(2):                       # twice: the second pass reuses cached allocations across the two streams
+        extract_clip_batch(frames, pcm, c3d, byola, fe, e2v, par, torch.cuda.Stream(device=dev))
+    torch.cuda.synchronize()
+    for b in range(B):
+        for a, c, name in zip(seq[b], par[b], ("video", "byol-a", "emotion2vec")):
+            assert float(a.abs().max()) > 0, name
+            assert torch.equal(a, c), f"clip {b} {name}: streamed extraction differs"
