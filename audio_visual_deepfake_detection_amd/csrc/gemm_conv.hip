@@ -145,7 +145,12 @@ __device__ __forceinline__ void tile_epilogue(floatx16 (&acc)[MI * NI], float* s
 
 // Up to 3 same-shape problems per launch (the q / k / v projections of an attention block): the exp10 GEMMs are
 // latency-bound (~9 us floor per launch at K = 256), so one 3x larger launch costs about as much as one small one.
-struct FwdPtrs { const float* x[3]; const float* w[3]; const float* bias[3]; const float* mask[3]; float* y[3]; float* ypre[3]; };
+struct FwdPtrs {
+  const float* x[3]; const float* w[3]; const float* bias[3]; const float* mask[3]; float* y[3]; float* ypre[3];
+  // optional fused residual epilogue (single-problem launches): yres = res + rscale[c] * rkeep[row / resT] * y
+  // (AffineDropPath + residual of the MLP half of a block); y itself may then be NULL (inference keeps only yres)
+  const float* res = nullptr; const float* rscale = nullptr; const float* rkeep = nullptr; float* yres = nullptr; int resT = 1;
+};
 struct DgradPtrs { const float* dy[3]; const float* w[3]; const float* mask[3]; const float* ypre[3]; float* dx[3]; };
 struct WgradPtrs { const float* dy[3]; const float* x[3]; const float* mask[3]; const float* ypre[3]; float* out[3]; float* dbias[3]; };
 template <class T>
@@ -371,8 +376,15 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
     }
   }
   AVDF_PROBE(14);
+  const float* __restrict__ res = ptrs.res;
+  const float* __restrict__ rscale = ptrs.rscale;
+  const float* __restrict__ rkeep = ptrs.rkeep;
+  float* __restrict__ yres = ptrs.yres;
+  const int resT = ptrs.resT;
   const bool vec = ((ldy & 3) == 0) && ((ybs & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
-                   (ypre == nullptr || (reinterpret_cast<uintptr_t>(ypre) & 15) == 0);
+                   (ypre == nullptr || (reinterpret_cast<uintptr_t>(ypre) & 15) == 0) &&
+                   (res == nullptr || (((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(yres) |
+                                         reinterpret_cast<uintptr_t>(rscale)) & 15) == 0));
   tile_epilogue<BM, BN, KG, WN, MI, NI>(acc, smem, kg, wm, wn, li, lh, tid, [&](int row_, int c, float4 v) {
     const int t = t0 + row_, n = n0 + c;
     if (t >= Tout || n >= Cout) return;
@@ -383,15 +395,25 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
       if (bias) { const float4 bb = ld4(bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
       if (ypre) *reinterpret_cast<float4*>(ypre + yrow + n) = v;
       v.x = act_f(v.x, act) * m; v.y = act_f(v.y, act) * m; v.z = act_f(v.z, act) * m; v.w = act_f(v.w, act) * m;
-      *reinterpret_cast<float4*>(y + yrow + n) = v;
+      if (y) *reinterpret_cast<float4*>(y + yrow + n) = v;
+      if (res) {
+        const float kp = rkeep ? rkeep[row / resT] : 1.f;
+        const float4 r4 = ld4(res + yrow + n), s4 = ld4(rscale + n);
+        float4 o;
+        o.x = r4.x + s4.x * kp * v.x; o.y = r4.y + s4.y * kp * v.y; o.z = r4.z + s4.z * kp * v.z; o.w = r4.w + s4.w * kp * v.w;
+        *reinterpret_cast<float4*>(yres + yrow + n) = o;
+      }
     } else {
       const float e[4] = {v.x, v.y, v.z, v.w};
+      const float kp = (res && rkeep) ? rkeep[row / resT] : 1.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (n + j >= Cout) break;
         float u = e[j] + (bias ? bias[n + j] : 0.f);
         if (ypre) ypre[yrow + n + j] = u;
-        y[yrow + n + j] = act_f(u, act) * m;
+        u = act_f(u, act) * m;
+        if (y) y[yrow + n + j] = u;
+        if (res) yres[yrow + n + j] = res[yrow + n + j] + rscale[n + j] * kp * u;
       }
     }
   });
@@ -1029,7 +1051,7 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
 }
 
 static FwdPtrs fwd_ptrs1(const float* x, const float* w, const float* bias, const float* mask, float* y, float* ypre) {
-  FwdPtrs g;
+  FwdPtrs g{};
   for (int i = 0; i < 3; ++i) { g.x[i] = x; g.w[i] = w; g.bias[i] = bias; g.mask[i] = mask; g.y[i] = y; g.ypre[i] = ypre; }
   return g;
 }
@@ -1046,6 +1068,25 @@ extern "C" int avdf_conv1d_fwd(const float* x, const float* w, const float* bias
   AVDF_REQUIRE(aligned16(x) && aligned16(w), "conv1d_fwd: x/w must be 16-byte aligned");
   return conv1d_fwd_launch(fwd_ptrs1(x, w, bias, mask, y, ypre), 1, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin,
                            Cin * K, Cout, act, (hipStream_t)stream);
+}
+
+// Dense conv + the block's second residual in one launch: h = (conv(x) + bias) * mask (stored to `y` unless y is NULL),
+// out = res + rscale[c] * rkeep[b] * h  (AffineDropPath + residual, blocks.py:1313 `out + drop_path_mlp(mlp(ln2(out)))`).
+// rkeep may be NULL (eval / no stochastic depth).  out must not alias x.
+extern "C" int avdf_conv1d_fwd_residual(const float* x, const float* w, const float* bias, const float* mask,
+                                        const float* res, const float* rscale, const float* rkeep, float* y, float* out,
+                                        int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, void* stream) {
+  AVDF_REQUIRE(x && w && res && rscale && out, "conv1d_fwd_residual: null pointer");
+  AVDF_REQUIRE(B > 0 && Tin > 0 && Cin > 0 && Tout > 0 && Cout > 0, "conv1d_fwd_residual: bad dims");
+  AVDF_REQUIRE((K == 1 || K == 3) && (stride == 1 || stride == 2) && !(K == 1 && stride != 1), "conv1d_fwd_residual: unsupported K/stride");
+  AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_fwd_residual: Cin, Cout must be multiples of 4 (%d, %d)", Cin, Cout);
+  AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_fwd_residual: Tout inconsistent");
+  AVDF_REQUIRE(aligned16(x) && aligned16(w) && aligned16(res) && aligned16(rscale) && aligned16(out) && aligned16(y),
+               "conv1d_fwd_residual: 16-byte alignment");
+  FwdPtrs g = fwd_ptrs1(x, w, bias, mask, y, nullptr);
+  g.res = res; g.rscale = rscale; g.rkeep = rkeep; g.yres = out; g.resT = Tout;
+  return conv1d_fwd_launch(g, 1, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin, Cin * K, Cout, AVDF_ACT_NONE,
+                           (hipStream_t)stream);
 }
 
 // Same-shape problems in one launch (n <= 3): q / k / v projections.  Tables of n device pointers; bias / mask /

@@ -305,6 +305,8 @@ class _BlockBase(nn.Module):
             out = ops.affine_residual(skip, out_mask, out, None, sa, ka)
             h = self.ln2(out)
         h = ops.conv1d(h, self.mlp[0].weight, self.mlp[0].bias, None, 1, ops.ACT_GELU)
+        if ops.FUSE_FC2_RESIDUAL and self.mlp[3].weight.shape[0] == out.shape[-1]:
+            return ops.conv1d_residual(h, self.mlp[3].weight, self.mlp[3].bias, out_mask, out, sm, km)
         h = ops.conv1d(h, self.mlp[3].weight, self.mlp[3].bias, out_mask)
         return ops.affine_residual(out, None, h, None, sm, km)
 

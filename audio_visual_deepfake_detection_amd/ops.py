@@ -278,6 +278,64 @@ def conv1d(x, w, bias=None, mask=None, stride=1, act=ACT_NONE, exact=False):
     return Conv1dFn.apply(x, w, bias, mask, stride, act)
 
 
+class _CtxProxy:
+    """Duck-typed ctx so that a composite Function can reuse Conv1dFn.backward."""
+
+    def __init__(self, saved, cfg, main, needs):
+        self.saved_tensors, self.cfg, self.main, self.needs_input_grad = saved, cfg, main, needs
+
+
+class Conv1dResidualFn(torch.autograd.Function):
+    """out = a + scale[c] * keep[b] * ((conv1d(x, w) + bias) * mask): the MLP's second linear layer with the block's
+    AffineDropPath + residual in the GEMM epilogue (blocks.py:1313).  Backward: da = dout; the gradient reaching the
+    conv output and dscale come from the affine-residual backward kernel, then the ordinary conv backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mask, a, scale, keep):
+        w0, b0 = w, bias
+        x, w, bias, mask, a, keep = _c(x), _c(w), _c(bias), _c(mask), _c(a), _c(keep)
+        B, Tin, Cin = x.shape
+        Cout, Cin_w, K = w.shape
+        assert Cin_w == Cin and a.shape == (B, Tin, Cout), (w.shape, x.shape, a.shape)
+        sc = scale.contiguous().view(-1)
+        need_h = any(ctx.needs_input_grad)
+        h = torch.empty((B, Tin, Cout), dtype=x.dtype, device=x.device) if need_h else None
+        out = torch.empty((B, Tin, Cout), dtype=x.dtype, device=x.device)
+        fl = 2.0 * B * Tin * Cout * Cin * K
+        _timed(_conv_tag("fwd", K, 1, B, Tin, Cout), fl, lambda: check(
+            lib.avdf_conv1d_fwd_residual(_p(x), _p(w), _p(bias), _p(mask), _p(a), _p(sc), _p(keep), _p(h), _p(out), B, Tin, Cin,
+                                         Tin, Cout, K, 1, _stream()), "conv1d_fwd_residual"), ("fwd", K, 1, B, Tin, Cin, Cout, 1))
+        ctx.save_for_backward(x, w, mask, h, sc, keep)
+        ctx.cfg = (B, Tin, Cin, Tin, Cout, K, 1, ACT_NONE, bias is not None)
+        ctx.main = (_main_grad(w0), _main_grad(b0))
+        ctx.smain, ctx.sshape = _main_grad(scale), scale.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, mask, h, sc, keep = ctx.saved_tensors
+        B, Tin, Cin, Tout, Cout, K, stride, act, has_bias = ctx.cfg
+        dout = dout.contiguous()
+        dh = torch.empty_like(h)
+        acc = 1 if ctx.smain is not None else 0
+        ds = None
+        if ctx.needs_input_grad[5]:
+            ds = ctx.smain.view(-1) if acc else torch.empty_like(sc)
+        ws = _ws(lib.avdf_affine_residual_bwd_ws(B, Tout, Cout), h) if ds is not None else None
+        check(lib.avdf_affine_residual_bwd(_p(dout), None, _p(h), None, _p(sc), _p(keep), None, _p(dh), _p(ds), _p(ws), B, Tout,
+                                           Cout, acc, _stream()), "affine_residual_bwd")
+        proxy = _CtxProxy((x, w, mask, None), ctx.cfg, ctx.main, ctx.needs_input_grad[0:3] + (False,) * 3)
+        dx, dw, db = Conv1dFn.backward(proxy, dh)[0:3]
+        return dx, dw, db, None, dout, None if (ds is None or acc) else ds.view(ctx.sshape), None
+
+
+FUSE_FC2_RESIDUAL = True   # blocks._residual_mlp: fc2 + AffineDropPath + residual as one launch
+
+
+def conv1d_residual(x, w, bias, mask, a, scale, keep=None):
+    return Conv1dResidualFn.apply(x, w, bias, mask, a, scale, keep)
+
+
 class Conv1dGroup3Fn(torch.autograd.Function):
     """Three same-shape dense convs (no mask, no activation) as ONE launch each for forward, dgrad and wgrad:
     the q / k / v 1x1 projections (blocks.py:1176-1178, 734-736)."""

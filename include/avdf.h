@@ -58,6 +58,13 @@ int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, const float* c
                                    int B, int Tin, int Cin, int Tout, int Cout, int K, int stride, int act,
                                    int accumulate, void* stream);
 
+/* avdf_conv1d_fwd with the block's second residual fused into the epilogue: h = (conv(x) + bias) * mask is stored to y
+ * (y may be NULL: inference), out = res + rscale[c] * rkeep[b] * h (rkeep may be NULL).  Replaces MaskedConv1D +
+ * AffineDropPath + the residual add of blocks.py:1313 / 872 (`out + self.drop_path_mlp(self.mlp(self.ln2(out)) * mask)`). */
+int avdf_conv1d_fwd_residual(const float* x, const float* w, const float* bias, const float* mask, const float* res,
+                             const float* rscale, const float* rkeep, float* y, float* out, int B, int Tin, int Cin,
+                             int Tout, int Cout, int K, int stride, void* stream);
+
 /* K=1 / stride-1 layers: data gradient (dx[i] overwritten) AND weight / bias gradient (ACCUMULATED into dw[i] /
  * dbias[i] with float atomics, as avdf_conv1d_bwd_weight_grouped with accumulate != 0) of n <= 3 same-shape problems
  * in one launch.  Replaces the two autograd nodes of nn.Conv1d(k=1) / nn.Linear backward in the reference's blocks

@@ -602,3 +602,38 @@ def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
         check(lib.avdf_bwd_pair_mode(1), "mode")
         for k in (0, 1, 2, 4):
             check(lib.avdf_gemm_override(k, -1, -1), "override")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,Cin,Cout,use_keep,masked", [(2, 96, 1024, 256, True, True), (8, 768, 64, 32, False, True),
+                                                         (3, 12, 256, 256, True, False), (1, 50, 36, 20, True, True)])
+def test_conv1d_residual_matches_separate_ops(ops, B, T, Cin, Cout, use_keep, masked):
+    """fc2 + AffineDropPath + residual in one launch (ops.conv1d_residual) == conv1d followed by affine_residual, and
+    == float64, forward and every gradient."""
+    x, w, bias = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, 1, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3, scale=0.1)
+    a, scale = rnd(B, T, Cout, seed=4), rnd(1, Cout, 1, seed=5, scale=0.5)
+    keep = (torch.tensor([1.25, 0.0, 1.25, 1.25, 0.0, 1.25, 1.25, 1.25][:B], dtype=torch.float64) if use_keep else None)
+    mask = mk_mask(B, T, [T - 2 * b for b in range(B)]) if masked else None
+    dout = rnd(B, T, Cout, seed=6)
+    # float64 reference
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, bias, a, scale)]
+    x6, w6, b6, a6, s6 = leaves
+    h = F.conv1d(x6.transpose(1, 2), w6, b6).transpose(1, 2)
+    if mask is not None:
+        h = h * mask[..., None]
+    ref = a6 + s6.view(1, 1, -1) * (keep.view(-1, 1, 1) if keep is not None else 1.0) * h
+    (ref * dout).sum().backward()
+    dl = [g32(t, True) for t in (x, w, bias, a, scale)]
+    got = ops.conv1d_residual(dl[0], dl[1], dl[2], None if mask is None else g32(mask), dl[3], dl[4],
+                              None if keep is None else g32(keep))
+    close(got, ref, "conv1d_residual out")
+    (got * g32(dout)).sum().backward()
+    for t32, t64, name in zip(dl, leaves, ("x", "w", "bias", "a", "scale")):
+        close(t32.grad, t64.grad, f"conv1d_residual d{name}", rtol=5e-5)
+    # the separate ops give the same forward values (same GEMM kernel, same epilogue arithmetic order)
+    with torch.no_grad():
+        sep = ops.affine_residual(dl[3], None, ops.conv1d(dl[0], dl[1], dl[2], None if mask is None else g32(mask)), None, dl[4],
+                                  None if keep is None else g32(keep))
+        fused = ops.conv1d_residual(dl[0], dl[1], dl[2], None if mask is None else g32(mask), dl[3], dl[4],
+                                    None if keep is None else g32(keep))
+    close(fused, sep.double().cpu(), "fused vs separate", rtol=1e-6)
