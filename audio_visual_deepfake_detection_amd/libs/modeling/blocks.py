@@ -21,9 +21,26 @@ from torch import nn
 from ... import ops
 
 
+_MASK_CACHE = {}
+
+
+def reset_mask_cache():
+    """Called at the start of every network forward: masks of one forward are memoised, never across forwards (the
+    engine's static mask buffer is refilled in place between steps)."""
+    _MASK_CACHE.clear()
+
+
 def downsample_mask(mask, stride):
-    """Nearest-neighbour mask downsampling of MaskedConv1D (blocks.py:51-55) == mask[:, ::stride]."""
-    return mask if stride == 1 else mask[:, ::stride].contiguous()
+    """Nearest-neighbour mask downsampling of MaskedConv1D (blocks.py:51-55) == mask[:, ::stride].  Every strided block
+    asks for the same pyramid masks (attention, pooling skip, MLP): one strided copy per (mask, stride) per forward."""
+    if stride == 1:
+        return mask
+    key = (mask.data_ptr(), tuple(mask.shape), tuple(mask.stride()), stride, mask._version)
+    hit = _MASK_CACHE.get(key)
+    if hit is None:
+        hit = (mask, mask[:, ::stride].contiguous())          # keeps `mask` alive: its address cannot be recycled
+        _MASK_CACHE[key] = hit
+    return hit[1]
 
 
 class MaskedConv1D(nn.Module):

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .models import register_meta_arch, make_backbone, make_neck, make_generator
-from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator, SegmentandCls
+from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator, SegmentandCls, reset_mask_cache
 from ... import ops
 
 
@@ -291,6 +291,7 @@ class AVPtTransformerRecovery(nn.Module):
     def forward_features(self, x, mask):
         """Network body on time-major tensors: returns (logits [B,P], offsets [B,P,2], pmask [B,P],
         video logits [B,1], per-level lengths)."""
+        reset_mask_cache()
         self._front_input = x
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
         feats, masks = self._run_backbone(x, reco_x, mask)
