@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   constexpr int A4 = KC / 4;
   constexpr int NA = (HV * A4 + 255) / 256, NB = (9 * BN * A4 + 255) / 256;
   constexpr int AS = (HV * LDA + 3) / 4 * 4;
-  // BF3: hi / lo bf16 planes, rows padded by 8 elements (conflict-free 16-byte fragment reads)
-  constexpr int LDH = KC + 8;
+  // BF3: hi / lo bf16 planes, rows of exactly KC elements; the 16-byte chunk index of a row is XOR-swizzled with bit 3
+  // of the row number (swz), so the 16 consecutive rows one quarter-wave reads land on 64 distinct banks without row
+  // padding: 58.6 KB instead of 87.9 KB per workgroup for the 64-channel layers = two workgroups per CU
+  constexpr int LDH = KC;
+  auto swz = [](int row, int chunk) { return chunk ^ ((row >> 3) & 1); };
   constexpr int ASH = HV * LDH, BSH = 9 * BN * LDH;
   static_assert(!BF3 || KC % 16 == 0, "bf16x3 needs 16-deep channel chunks");
   constexpr int SMF = BF3 ? (ASH + BSH) : (AS + 9 * BN * LDB);
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   for (int mi = 0; mi < MI; ++mi) {
     const int m = (wm * MI + mi) * 32 + li;
     const int pt = m / (TH * TW), ph = (m / TW) % TH, pw = m % TW;
-    abase[mi] = ((pt * HH + ph) * HW + pw) * (BF3 ? LDH : LDA) + (BF3 ? lh * 8 : lh);
+    abase[mi] = BF3 ? ((pt * HH + ph) * HW + pw) : ((pt * HH + ph) * HW + pw) * LDA + lh;     // BF3: the patch ROW (swizzled per read)
   }
 
   F4Buf<NA> ra;
@@ -123,8 +126,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
         if (BF3) {
           uint2 hi, lo;
           split_bf16x4(ra.v[i], hi, lo);
-          *reinterpret_cast<uint2*>(Ah + (q / A4) * LDH + (q % A4) * 4) = hi;
-          *reinterpret_cast<uint2*>(Al + (q / A4) * LDH + (q % A4) * 4) = lo;
+          const int row = q / A4, c4 = q % A4;
+          const int off = row * LDH + swz(row, c4 >> 1) * 8 + (c4 & 1) * 4;
+          *reinterpret_cast<uint2*>(Ah + off) = hi;
+          *reinterpret_cast<uint2*>(Al + off) = lo;
         } else {
           float* d = As + (q / A4) * LDA + (q % A4) * 4;
           d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
@@ -138,8 +143,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
         if (BF3) {
           uint2 hi, lo;
           split_bf16x4(rb.v[i], hi, lo);
-          *reinterpret_cast<uint2*>(Bh + (q / A4) * LDH + (q % A4) * 4) = hi;
-          *reinterpret_cast<uint2*>(Bl + (q / A4) * LDH + (q % A4) * 4) = lo;
+          const int row = q / A4, c4 = q % A4;
+          const int off = row * LDH + swz(row, c4 >> 1) * 8 + (c4 & 1) * 4;
+          *reinterpret_cast<uint2*>(Bh + off) = hi;
+          *reinterpret_cast<uint2*>(Bl + off) = lo;
         } else {
           float* d = Bs + (q / A4) * LDB + (q % A4) * 4;
           d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
@@ -156,18 +163,21 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
     if constexpr (BF3) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int aoff = ((tap / 3) * HW + (tap % 3)) * LDH;
+        const int arow_off = (tap / 3) * HW + (tap % 3);
 #pragma unroll
         for (int cc = 0; cc < KC; cc += 16) {
           bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
-            ah[mi] = *reinterpret_cast<const bf16x8*>(Ah + abase[mi] + aoff + cc);
-            al[mi] = *reinterpret_cast<const bf16x8*>(Al + abase[mi] + aoff + cc);
+            const int row = abase[mi] + arow_off;
+            const int off = row * LDH + swz(row, cc / 8 + lh) * 8;
+            ah[mi] = *reinterpret_cast<const bf16x8*>(Ah + off);
+            al[mi] = *reinterpret_cast<const bf16x8*>(Al + off);
           }
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            const int off = (tap * BN + (wn * NI + ni) * 32 + li) * LDH + cc + lh * 8;
+            const int row = tap * BN + (wn * NI + ni) * 32 + li;
+            const int off = row * LDH + swz(row, cc / 8 + lh) * 8;
             bh[ni] = *reinterpret_cast<const bf16x8*>(Bh + off);
             bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
           }
