@@ -85,6 +85,7 @@ SIGNATURES = {
     "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
     "avdf_wave_conv_c1": (I, [P, P, P, L, L, I, I, I, P]),
     "avdf_grouped_conv_pos": (I, [P, P, P, P, I, I, I, I, P]),
+    "avdf_grouped_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "avdf_residual_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P]),
     "avdf_residual_ln_bwd_ws": (L, [I, I, I]),
     "avdf_residual_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -150,6 +150,7 @@ struct FwdPtrs {
   // optional fused residual epilogue (single-problem launches): yres = res + rscale[c] * rkeep[row / resT] * y
   // (AffineDropPath + residual of the MLP half of a block); y itself may then be NULL (inference keeps only yres)
   const float* res = nullptr; const float* rscale = nullptr; const float* rkeep = nullptr; float* yres = nullptr; int resT = 1;
+  long bbs = 0;            // bias batch stride in floats (grouped convs: batch = channel group)
 };
 struct DgradPtrs { const float* dy[3]; const float* w[3]; const float* mask[3]; const float* ypre[3]; float* dx[3]; };
 struct WgradPtrs { const float* dy[3]; const float* x[3]; const float* mask[3]; const float* ypre[3]; float* out[3]; float* dbias[3]; };
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
   const float* __restrict__ rkeep = ptrs.rkeep;
   float* __restrict__ yres = ptrs.yres;
   const int resT = ptrs.resT;
+  const float* __restrict__ biasb = bias ? bias + (size_t)b * ptrs.bbs : nullptr;
   const bool vec = ((ldy & 3) == 0) && ((ybs & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
                    (ypre == nullptr || (reinterpret_cast<uintptr_t>(ypre) & 15) == 0) &&
                    (res == nullptr || (((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(yres) |
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
     const size_t yrow = (size_t)b * ybs + (size_t)t * ldy;
     const float m = mask ? mask[row] : 1.f;
     if (vec && n + 3 < Cout) {
-      if (bias) { const float4 bb = ld4(bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+      if (bias) { const float4 bb = ld4(biasb + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
       if (ypre) *reinterpret_cast<float4*>(ypre + yrow + n) = v;
       v.x = act_f(v.x, act) * m; v.y = act_f(v.y, act) * m; v.z = act_f(v.z, act) * m; v.w = act_f(v.w, act) * m;
       if (y) *reinterpret_cast<float4*>(y + yrow + n) = v;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (n + j >= Cout) break;
-        float u = e[j] + (bias ? bias[n + j] : 0.f);
+        float u = e[j] + (bias ? biasb[n + j] : 0.f);
         if (ypre) ypre[yrow + n + j] = u;
         u = act_f(u, act) * m;
         if (y) y[yrow + n + j] = u;
@@ -1041,7 +1043,10 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
                        0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad, ldx, ldw, ldy, xbs, wbs, \
                        ybs);                                                                            \
   } while (0)
-  if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
+  if (K == 19 && stride == 1) {          // Emotion2Vec positional grouped conv: 64x64 tile only (the 19-tap B tile is 78 KB)
+    if (plan.kg >= 2) LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 2); else LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 1);
+  }
+  else if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
   else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
   else if (K == 2 && stride == 2) { AVDF_GEMM_DISPATCH(2, 2, 64, 64, 64, 64, 32, 64, 2, LAUNCH_FWD) }
   else { AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, 128, 1, LAUNCH_FWD) }
@@ -1087,6 +1092,22 @@ extern "C" int avdf_conv1d_fwd_residual(const float* x, const float* w, const fl
   g.res = res; g.rscale = rscale; g.rkeep = rkeep; g.yres = out; g.resT = Tout;
   return conv1d_fwd_launch(g, 1, B, Tin, Cin, Tout, Cout, K, stride, K / 2, Cin, Cin * K, Cout, AVDF_ACT_NONE,
                            (hipStream_t)stream);
+}
+
+// Grouped "same" conv over time on the MFMA GEMM: x, y [T, C] time-major, w [C][C/groups][K] (torch Conv1d(groups=g) layout),
+// bias [C]; every channel group is one batch entry of the strided forward kernel (column slices of x / y, its own weight
+// and bias block).  K = 19 only: the positional conv of Emotion2Vec / data2vec-2.0 (fairseq `make_conv_pos`, k=19, g=16).
+extern "C" int avdf_grouped_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int T, int C, int groups,
+                                       int K, void* stream) {
+  AVDF_REQUIRE(x && w && y && T > 0 && C > 0 && groups > 0 && C % groups == 0, "grouped_conv1d_fwd: bad args");
+  AVDF_REQUIRE(K == 19, "grouped_conv1d_fwd: K must be 19 (K=%d)", K);
+  const int Cg = C / groups;
+  AVDF_REQUIRE(Cg % 4 == 0 && C % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias),
+               "grouped_conv1d_fwd: channels per group must be a multiple of 4, 16-byte aligned operands");
+  FwdPtrs g = fwd_ptrs1(x, w, bias, nullptr, y, nullptr);
+  g.bbs = Cg;
+  return conv1d_fwd_launch(g, 1, groups, T, Cg, T, Cg, K, 1, K / 2, C, Cg * K, C, AVDF_ACT_NONE, (hipStream_t)stream,
+                           (long)Cg, (long)Cg * Cg * K, (long)Cg);
 }
 
 // Same-shape problems in one launch (n <= 3): q / k / v projections.  Tables of n device pointers; bias / mask /

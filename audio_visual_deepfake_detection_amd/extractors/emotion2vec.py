@@ -202,9 +202,12 @@ class Emotion2Vec(nn.Module):
         for i in range(1, len(enc.relative_positional_encoder) - 1):
             conv = enc.relative_positional_encoder[i][0]
             y = torch.zeros((Tp, D), dtype=torch.float32, device=dev)
-            check(lib.avdf_grouped_conv_pos(h.data_ptr(), conv.weight.contiguous().data_ptr(), conv.bias.data_ptr(),
-                                            y.data_ptr(), T, D, self.conv_pos_groups, conv.weight.shape[2], st),
-                  "grouped_conv_pos")
+            kpos = conv.weight.shape[2]
+            # k=19 / 16 groups (every released checkpoint): each group is a 48-channel GEMM slice on the MFMA kernel
+            # (2.15 GF per layer: 290 -> ~50 us); other kernel sizes keep the scalar kernel
+            fn = lib.avdf_grouped_conv1d_fwd if (kpos == 19 and (D // self.conv_pos_groups) % 4 == 0) else lib.avdf_grouped_conv_pos
+            check(fn(h.data_ptr(), conv.weight.contiguous().data_ptr(), conv.bias.data_ptr(), y.data_ptr(), T, D,
+                     self.conv_pos_groups, kpos, st), "grouped_conv_pos")
             h = torch.zeros_like(y)
             h[:T] = ops.layernorm(y[:T], None, None, 1e-5, 2)                # LN (no affine) + GELU
         x = ops.affine_residual(xp.unsqueeze(0), None, h.unsqueeze(0), None, self._ones)[0]

@@ -298,6 +298,9 @@ int avdf_wave_conv_c1(const float* pcm, const float* w, float* y, int64_t n_samp
                       int K, int stride, void* stream);
 int avdf_grouped_conv_pos(const float* x, const float* w, const float* bias, float* y, int T, int C,
                           int groups, int K, void* stream);
+/* avdf_grouped_conv_pos on the MFMA GEMM (K = 19): every channel group is one batch entry of the strided forward kernel. */
+int avdf_grouped_conv1d_fwd(const float* x, const float* w, const float* bias, float* y, int T, int C, int groups, int K,
+                            void* stream);
 int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream);
 /* all H heads of a layer in one launch: scores [H][T][ld] with `head_stride` floats between heads, slopes [H] (device) */
 int avdf_softmax_alibi_heads(float* scores, int H, int T, int ld, int64_t head_stride, float qk_scale,
