@@ -32,6 +32,31 @@ __global__ __launch_bounds__(256) void wave_conv_c1_kernel(const float* __restri
   }
 }
 
+// same, K <= 16 and C/4 a divisor of 256: a thread keeps the K taps of its 4 channels in registers and walks over
+// tokens, so the kernel is bound by the 2 KB output row per token (201 MB per 768-frame clip), not by weight re-loads
+__global__ __launch_bounds__(256) void wave_conv_c1_reg_kernel(const float* __restrict__ pcm, const float* __restrict__ w,
+                                                               float* __restrict__ y, long T, int C, int K, int S) {
+  const int C4 = C >> 2, lanes = 256 / C4;
+  const int n = (threadIdx.x % C4) * 4, tl = threadIdx.x / C4;
+  float wr[4][16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wr[j][k] = k < K ? w[(n + j) * K + k] : 0.f;
+  for (long t = (long)blockIdx.x * lanes + tl; t < T; t += (long)gridDim.x * lanes) {
+    const float* px = pcm + t * S;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < K) {
+        const float xv = px[k];
+        acc.x += xv * wr[0][k]; acc.y += xv * wr[1][k]; acc.z += xv * wr[2][k]; acc.w += xv * wr[3][k];
+      }
+    }
+    st4(y + t * C + n, acc);
+  }
+}
+
 // y[t, g*CG + co] = bias + sum_{ci<CG, k<K} x[t + k - K/2, g*CG + ci] * w[g*CG + co, ci, k]
 // one workgroup = (32-token tile, group); threads = CG output channels x 256/CG token lanes; x tile in LDS
 template <int CG, int K>
@@ -113,8 +138,16 @@ extern "C" int avdf_wave_conv_c1(const float* pcm, const float* w, float* y, int
                                  int K, int stride, void* stream) {
   AVDF_REQUIRE(pcm && w && y && Tout > 0 && C > 0 && C % 4 == 0 && K > 0 && stride > 0, "wave_conv_c1: bad args");
   AVDF_REQUIRE((Tout - 1) * stride + K <= n_samples, "wave_conv_c1: Tout exceeds the valid-conv length");
-  hipLaunchKernelGGL(wave_conv_c1_kernel, dim3(grid_for(Tout * C / 4)), dim3(256), 0, (hipStream_t)stream, pcm, w, y,
-                     (long)Tout, C, K, stride);
+  if (K <= 16 && C / 4 <= 256 && 256 % (C / 4) == 0) {
+    const long lanes = 256 / (C / 4);
+    long blocks = (Tout + lanes - 1) / lanes;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wave_conv_c1_reg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pcm, w, y,
+                       (long)Tout, C, K, stride);
+  } else {
+    hipLaunchKernelGGL(wave_conv_c1_kernel, dim3(grid_for(Tout * C / 4)), dim3(256), 0, (hipStream_t)stream, pcm, w, y,
+                       (long)Tout, C, K, stride);
+  }
   AVDF_CHECK_LAUNCH("wave_conv_c1");
   return AVDF_OK;
 }
