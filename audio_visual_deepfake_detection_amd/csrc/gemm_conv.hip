@@ -1044,7 +1044,8 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
                        ybs);                                                                            \
   } while (0)
   if (K == 19 && stride == 1) {          // Emotion2Vec positional grouped conv: 64x64 tile only (the 19-tap B tile is 78 KB)
-    if (plan.kg >= 2) LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 2); else LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 1);
+    // split-bf16 needs 16-deep k-steps per K-group: one K-group in that mode
+    if (plan.kg >= 2 && g_gemm_mode != 1) LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 2); else LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 1);
   }
   else if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
   else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
