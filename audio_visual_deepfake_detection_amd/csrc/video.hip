@@ -285,6 +285,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 static int g_c3d_mode = 0;      // 0 exact fp32 MFMA, 1 split-bf16 operands (layers with Cin >= 16)
+static int g_c3d_n96_small = [] { const char* e = getenv("AVDF_C3D_N96_SMALL"); return e ? atoi(e) : 1; }();
 extern "C" int avdf_conv3d_mode(int mode) {
   AVDF_REQUIRE(mode == 0 || mode == 1, "conv3d_mode: 0 (fp32) or 1 (bf16x3)");
   g_c3d_mode = mode;
@@ -321,10 +322,14 @@ extern "C" int avdf_conv3d_k3(const float* x, const float* wp, const float* bias
     if (W >= 32) LAUNCH_C3(1, 8, 32, 4, 1, 2, 2, 4);
     else LAUNCH_C3(4, 4, 4, 2, 2, 1, 1, 4);
   } else if (W >= 32) {
-    if (n96) LAUNCH_C3(1, 8, 32, 4, 1, 2, 3, 16);
+    // 96 output channels: 6 accumulator tiles per wave need 320 registers (one workgroup per CU); in split-bf16 mode
+    // a 128-voxel tile (3 accumulator tiles) fits two workgroups per CU
+    if (n96 && g_c3d_mode == 1 && g_c3d_n96_small) LAUNCH_C3(1, 8, 16, 4, 1, 1, 3, 16);
+    else if (n96) LAUNCH_C3(1, 8, 32, 4, 1, 2, 3, 16);
     else LAUNCH_C3(1, 8, 32, 4, 1, 2, 2, 16);
   } else if (W >= 16) {
-    if (n96) LAUNCH_C3(1, 16, 16, 4, 1, 2, 3, 16);
+    if (n96 && g_c3d_mode == 1 && g_c3d_n96_small) LAUNCH_C3(1, 8, 16, 4, 1, 1, 3, 16);
+    else if (n96) LAUNCH_C3(1, 16, 16, 4, 1, 2, 3, 16);
     else LAUNCH_C3(1, 16, 16, 4, 1, 2, 2, 16);
   } else if (W >= 8) {
     LAUNCH_C3(2, 8, 8, 2, 2, 2, 1, 16);
