@@ -125,6 +125,61 @@ __global__ __launch_bounds__(256) void softmax_alibi_kernel(float* __restrict__ 
   for (int j = lane; j < ld; j += 64) row[j] = j < T ? row[j] * inv : 0.f;
 }
 
+// same, the row held in registers (ld % 4 == 0, ld <= 256 * NV): one 16-byte read and one 16-byte write per element
+// group instead of three scalar read-modify-write passes through L2
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_alibi_reg_kernel(float* __restrict__ s, int T, int ld, float qk_scale,
+                                                                const float* __restrict__ slopes, float slope, long hstride) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= T) return;
+  if (slopes) slope = slopes[blockIdx.y];
+  float* row = s + (size_t)blockIdx.y * hstride + (size_t)i * ld;
+  float v[NV][4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int j4 = (q * 64 + lane) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j4 < ld) x = *reinterpret_cast<const float4*>(row + j4);
+    const float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j4 + u;
+      v[q][u] = j < T ? e[u] * qk_scale - slope * fabsf((float)(i - j)) : -INFINITY;
+      m = fmaxf(m, v[q][u]);
+    }
+  }
+  m = wave_max(m);
+  float den = 0.f;
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[q][u] = __expf(v[q][u] - m);          // exp(-inf) = 0 for the padding columns
+      den += v[q][u];
+    }
+  den = wave_sum(den);
+  const float inv = 1.0f / den;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const int j4 = (q * 64 + lane) * 4;
+    if (j4 < ld) *reinterpret_cast<float4*>(row + j4) = make_float4(v[q][0] * inv, v[q][1] * inv, v[q][2] * inv, v[q][3] * inv);
+  }
+}
+
+static void launch_softmax_alibi(float* scores, int H, int T, int ld, long hstride, float qk_scale, const float* slopes,
+                                 float slope, hipStream_t st) {
+  const dim3 grid((T + 3) / 4, H);
+  const bool vec = (ld % 4 == 0) && (hstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
+  const int nv = (ld + 255) / 256;
+  if (vec && nv <= 2) hipLaunchKernelGGL(softmax_alibi_reg_kernel<2>, grid, dim3(256), 0, st, scores, T, ld, qk_scale, slopes, slope, hstride);
+  else if (vec && nv <= 4) hipLaunchKernelGGL(softmax_alibi_reg_kernel<4>, grid, dim3(256), 0, st, scores, T, ld, qk_scale, slopes, slope, hstride);
+  else if (vec && nv <= 6) hipLaunchKernelGGL(softmax_alibi_reg_kernel<6>, grid, dim3(256), 0, st, scores, T, ld, qk_scale, slopes, slope, hstride);
+  else if (vec && nv <= 8) hipLaunchKernelGGL(softmax_alibi_reg_kernel<8>, grid, dim3(256), 0, st, scores, T, ld, qk_scale, slopes, slope, hstride);
+  else hipLaunchKernelGGL(softmax_alibi_kernel, grid, dim3(256), 0, st, scores, T, ld, qk_scale, slopes, slope, hstride);
+}
+
 inline int grid_for(long total) {
   long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
@@ -164,8 +219,7 @@ extern "C" int avdf_grouped_conv_pos(const float* x, const float* w, const float
 
 extern "C" int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope, void* stream) {
   AVDF_REQUIRE(scores && T > 0 && ld >= T, "softmax_alibi: bad args");
-  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, scores, T, ld, qk_scale,
-                     (const float*)nullptr, slope, 0L);
+  launch_softmax_alibi(scores, 1, T, ld, 0L, qk_scale, nullptr, slope, (hipStream_t)stream);
   AVDF_CHECK_LAUNCH("softmax_alibi");
   return AVDF_OK;
 }
@@ -174,8 +228,7 @@ extern "C" int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, 
 extern "C" int avdf_softmax_alibi_heads(float* scores, int H, int T, int ld, int64_t head_stride, float qk_scale,
                                         const float* slopes, void* stream) {
   AVDF_REQUIRE(scores && slopes && H > 0 && T > 0 && ld >= T && head_stride >= (int64_t)T * ld, "softmax_alibi_heads: bad args");
-  hipLaunchKernelGGL(softmax_alibi_kernel, dim3(cdiv(T, 4), H), dim3(256), 0, (hipStream_t)stream, scores, T, ld, qk_scale,
-                     slopes, 0.f, (long)head_stride);
+  launch_softmax_alibi(scores, H, T, ld, (long)head_stride, qk_scale, slopes, 0.f, (hipStream_t)stream);
   AVDF_CHECK_LAUNCH("softmax_alibi_heads");
   return AVDF_OK;
 }

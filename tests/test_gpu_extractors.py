@@ -243,3 +243,26 @@ def test_extract_clip_batch_streams_equal_sequential():
         for a, c, name in zip(seq[b], par[b], ("video", "byol-a", "emotion2vec")):
             assert float(a.abs().max()) > 0, name
             assert torch.equal(a, c), f"clip {b} {name}: streamed extraction differs"
+
+
+@pytest.mark.parametrize("H,T,ld", [(3, 27, 28), (12, 1535, 1536), (2, 700, 704), (2, 1100, 1100), (1, 2040, 2048), (1, 2100, 2112),
+                                    (2, 50, 51)])
+def test_softmax_alibi_heads_all_paths(H, T, ld):
+    """softmax_j(S*scale - slope_h*|i-j|) in place, padding columns zeroed: the register-resident kernels (ld <= 2048,
+    ld % 4 == 0: 2 / 4 / 6 / 8 float4 per lane) and the scalar fallback (odd ld, ld > 2048) against float64."""
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(T)
+    s = torch.randn(H, T, ld, generator=g) * 3.0
+    slopes = torch.tensor([2.0 ** (-(h + 1)) for h in range(H)])
+    qk = 0.125
+    i = torch.arange(T)[:, None].double()
+    j = torch.arange(T)[None, :].double()
+    ref = torch.softmax(s[:, :, :T].double() * qk - slopes.double()[:, None, None] * (i - j).abs(), dim=-1)
+    sd = s.to(dev).contiguous()
+    sl = slopes.to(dev)
+    check(lib.avdf_softmax_alibi_heads(sd.data_ptr(), H, T, ld, T * ld, qk, sl.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "softmax_alibi_heads")
+    out = sd.cpu().double()
+    assert float((out[:, :, :T] - ref).abs().max()) < 2e-6
+    assert float(out[:, :, T:].abs().max()) == 0.0 if ld > T else True
