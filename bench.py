@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--bf16x3-fwd", action="store_true",
                     help="training forward GEMMs with split-bf16 operands (707 vs 662 clips/s; losses agree to 1e-6, gradient "
                          "elements to ~5e-3 instead of 1e-4 -- not the parity-checked default)")
+    ap.add_argument("--workload", default="av", choices=["av", "audio"],
+                    help="av: exp10 AV fusion, C_in = 3072 (headline; BASELINE configs 3/4); audio: BYOL-A-only features, "
+                         "C_in = 2048 (BASELINE config 2) through the same exp10 architecture")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "e2e"],
                     help="train (headline), infer (K1 -> fwd -> decode+NMS), e2e (raw PCM + frames -> 3 encoders -> infer)")
     args = ap.parse_args()
@@ -165,7 +168,13 @@ def main():
 
     ops.BRANCH_STREAMS = args.branch_streams
     torch.manual_seed(0)                       # identical random-init weights on every rank
-    model, cfg = build_model("deepfake_exp10.yaml")
+    global STREAMS
+    if args.workload == "audio":
+        assert args.mode != "e2e", "--workload audio has no raw-media mode"
+        STREAMS = [STREAMS[1]]
+        model, cfg = build_model("deepfake_exp10.yaml", video_input_dim=0, audio_input_dim=2048)
+    else:
+        model, cfg = build_model("deepfake_exp10.yaml")
     model = model.to(dev)
     torch.manual_seed(1234 + rank)             # rank-offset drop-path / dropout streams
 
@@ -273,12 +282,14 @@ def main():
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "exp10 AV-fusion UMMAFormer training step (K1 interp -> fwd -> losses -> bwd -> "
-                                   "clip+AdamW+EMA), T=768, C_in=3072 (LAV-DF 256 + BYOL-A 2048 + Emotion2Vec 768), "
-                                   "random-init weights" if args.mode == "train" else
+            "config": {"workload": "exp10 UMMAFormer training step (K1 interp -> fwd -> losses -> bwd -> "
+                                   "clip+AdamW+EMA), T=768, C_in=%d, random-init weights" % sum(c for _, c in STREAMS)
+                                   if args.mode == "train" else
                                    ("exp10 AV-fusion UMMAFormer inference (K1 interp -> fwd -> decode+NMS)" if args.mode == "infer"
                                     else "raw PCM (491520 samples) + 768x224x224 u8 frames -> log-mel/BYOL-A + Emotion2Vec + C3D "
                                          "-> K1 -> exp10 UMMAFormer inference -> decode+NMS, random-init weights"),
+                       "features": ("LAV-DF 256 + BYOL-A 2048 + Emotion2Vec 768" if args.workload == "av"
+                                    else "BYOL-A 2048 only (BASELINE config 2 shapes: C_in = 2048 through the exp10 architecture)"),
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": 768,
                        "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
                        "fwd_gemm": ("bf16x3" if (args.mode != "train" or args.bf16x3_fwd) else "f32"), "bwd_gemm": "f32",
