@@ -111,3 +111,31 @@ def test_infer_step_equals_eval_model():
         assert n == res["segments"].shape[0]
         assert sorted(pidx[b, :n].tolist()) == sorted(res["kept_points"].tolist())
         assert torch.allclose(scores[b, :n].cpu().sort().values, res["scores"].sort().values, atol=1e-5)
+
+
+def test_audio_only_workload_steps():
+    """bench.py --workload audio (BASELINE config 2 shapes): one feature stream, video_input_dim = 0 -- the engine takes a
+    single-stream K1 and the step stays finite and changes the weights."""
+    from audio_visual_deepfake_detection_amd import build_model
+    from audio_visual_deepfake_detection_amd.engine import TrainStep
+    torch.manual_seed(3)
+    small = dict(SMALL, video_input_dim=0, audio_input_dim=64)
+    model, cfg = build_model("deepfake_exp10.yaml", **small)
+    model = model.to("cuda:0")
+    eng = TrainStep(model, 2, [(96, 64)], lr=1e-3, use_graph=True)
+    g = torch.Generator().manual_seed(5)
+    for b in range(2):
+        eng.streams[b][0].copy_(torch.randn(96, 64, generator=g))
+        eng.gt[b].zero_()
+        eng.ngt[b] = 0
+    eng.gt[0, 0] = torch.tensor([30.0, 80.0])
+    eng.ngt[0] = 1
+    eng.capture()
+    before = eng.flat_p.clone()
+    for _ in range(2):
+        eng.step()
+    torch.cuda.synchronize()
+    ls = eng.losses()
+    assert all(np.isfinite(v) for v in ls.values()), ls
+    assert ls["num_pos"] > 0
+    assert float((eng.flat_p - before).abs().max()) > 0
