@@ -7,6 +7,11 @@ interpolate on the CPU.  It returns the trimmed raw streams (`streams`: list of 
 random crop window (`crop`), and the meta-arch's preprocessing runs the K1 interpolation+concat kernel on the
 device and applies the crop there (the reference spends 65 ms/clip of CPU time on this,
 deepfake_video_audio.py:1722-1756).  No HIP call happens in a DataLoader worker.
+
+Items are `ClipItem` dicts: every key of the reference's item dict (deepfake_video_audio.py:1820-1830) is there, and
+`item['feats']` ([C, T] fp32, the reference's interpolated + concatenated + cropped matrix) is produced on first
+access for consumers written against the reference dict -- in the loader process, where the reference computes it.
+This package's own model never reads it (it takes `streams` + `crop`).  `return_feats=True` materialises it eagerly.
 """
 import json
 import os
@@ -19,6 +24,36 @@ from .datasets import register_dataset
 from .data_utils import truncate_window
 
 BYOLA_FPS, EMOTION_FPS = 12.497, 50            # deepfake_video_audio.py:1547-1548
+
+
+def interp_concat_host(streams, out_len, crop=None):
+    """The interpolation block of the reference's `__getitem__` (deepfake_video_audio.py:1722-1756, :1017-1040 for the
+    two-stream exp5 class) for readers of `item['feats']`: every stream transposed to [C_s, T_s], linearly resampled to
+    `out_len` (align_corners=False; the video stream only when its length differs), concatenated on channels, then the
+    crop window of truncate_feats (data_utils.py:124).  Host-side loader work, as in the reference; the model path runs
+    the K1 kernel on the device instead."""
+    import torch.nn.functional as F
+    outs = []
+    for i, arr in enumerate(streams):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(arr, np.float32).transpose()))
+        if i > 0 or t.shape[-1] != out_len:
+            t = F.interpolate(t.unsqueeze(0), size=out_len, mode='linear', align_corners=False).squeeze(0)
+        outs.append(t)
+    feats = torch.cat(outs, dim=0)
+    if crop is not None:
+        feats = feats[:, crop[0]:crop[1]].clone()
+    return feats
+
+
+class ClipItem(dict):
+    """Item dict with a lazily computed `feats` entry (see the module docstring)."""
+
+    def __missing__(self, key):
+        if key != 'feats':
+            raise KeyError(key)
+        feats = interp_concat_host(self['streams'], self['_max_seq_len'], self.get('crop'))
+        self['feats'] = feats
+        return feats
 
 
 def _av_labels(name):
@@ -48,6 +83,7 @@ class _TrainBase(Dataset):
         self.num_classes, self.file_prefix = num_classes, file_prefix or ''
         self.file_ext, self.audio_file_ext, self.force_upsampling = file_ext, audio_file_ext, force_upsampling
         self.label_dict = {'Fake': 0}
+        self.return_feats = getattr(self, 'return_feats', False)
         with open(train_txt, 'r') as f:
             self.data_list = [line.strip() for line in f.readlines()]
         self.db_attributes = {'dataset_name': 'DeepFake_Audio', 'tiou_thresholds': np.linspace(0.5, 0.95, 10),
@@ -109,10 +145,13 @@ class _TrainBase(Dataset):
             st, ed, segments, labels = truncate_window(feat_len, segments, labels, self.max_seq_len, self.trunc_thresh,
                                                        feat_offset, self.crop_ratio)
             crop = (st, ed)
-        out = {'video_id': rel.replace('.json', '.mp4'), 'streams': streams, 'crop': crop, 'segments': segments,
-               'n_fakes': 0 if segments is None else segments.shape[0], 'labels': labels,
-               'av_labels': torch.tensor(_av_labels(rel)), 'fps': item['fps'], 'duration': item['duration'],
-               'feat_stride': feat_stride, 'split': item['split'], 'feat_num_frames': num_frames}
+        out = ClipItem({'video_id': rel.replace('.json', '.mp4'), 'streams': streams, 'crop': crop, 'segments': segments,
+                        'n_fakes': 0 if segments is None else segments.shape[0], 'labels': labels,
+                        'av_labels': torch.tensor(_av_labels(rel)), 'fps': item['fps'], 'duration': item['duration'],
+                        'feat_stride': feat_stride, 'split': item['split'], 'feat_num_frames': num_frames,
+                        '_max_seq_len': self.max_seq_len})
+        if self.return_feats:
+            out['feats']
         if self.frame_labels:
             out['gt_frame_labels'] = None
             if self.is_training and segments is not None:
@@ -137,8 +176,9 @@ class DeepFakeVideoAudioDataset(_TrainBase):
                  audio_emo_feat_folder=None, train_txt=None, json_folder=None, feat_stride=1, num_frames=1,
                  default_fps=None, downsample_rate=0, max_seq_len=768, trunc_thresh=0.5, crop_ratio=None,
                  video_input_dim=256, audio_input_dim=2816, num_classes=1, file_prefix=None, file_ext='.npy',
-                 audio_file_ext='.npy', force_upsampling=True):
+                 audio_file_ext='.npy', force_upsampling=True, return_feats=False):
         self.video_feat_folder = video_feat_folder
+        self.return_feats = return_feats
         self.audio_byola_feat_folder, self.audio_emo_feat_folder = audio_byola_feat_folder, audio_emo_feat_folder
         self._setup(is_training, split, train_txt, json_folder, feat_stride, num_frames, default_fps, downsample_rate,
                     max_seq_len, trunc_thresh, crop_ratio, video_input_dim, audio_input_dim, num_classes, file_prefix,
@@ -167,8 +207,9 @@ class DeepFakeVideoEmoDataset(_TrainBase):
 
     def __init__(self, is_training, split, video_feat_folder, audio_feat_folder, train_txt, json_folder, feat_stride,
                  num_frames, default_fps, downsample_rate, max_seq_len, trunc_thresh, crop_ratio, video_input_dim,
-                 audio_input_dim, num_classes, file_prefix, file_ext, audio_file_ext, force_upsampling):
+                 audio_input_dim, num_classes, file_prefix, file_ext, audio_file_ext, force_upsampling, return_feats=False):
         self.video_feat_folder, self.audio_feat_folder = video_feat_folder, audio_feat_folder
+        self.return_feats = return_feats
         self._setup(is_training, split, train_txt, json_folder, feat_stride, num_frames, default_fps, downsample_rate,
                     max_seq_len, trunc_thresh, crop_ratio, video_input_dim, audio_input_dim, num_classes, file_prefix,
                     file_ext, audio_file_ext, force_upsampling)
@@ -190,9 +231,9 @@ class DeepFakeVideoAudioDatasetInfer3(Dataset):
                  video_feat_folder=None, audio_feat_folder=None, audio_byola_feat_folder=None,
                  audio_emo_feat_folder=None, audio_file_ext='.npy', num_classes=1, input_dim=0, video_input_dim=256,
                  audio_input_dim=2816, feat_stride=1, num_frames=1, test_folder=None, trunc_thresh=0.5,
-                 max_seq_len=768, force_upsampling=True, **_unused):
+                 max_seq_len=768, force_upsampling=True, return_feats=False, **_unused):
         assert num_classes == 1 and feat_stride > 0 and force_upsampling
-        self.sub_index, self.test_folder = sub_index, test_folder
+        self.sub_index, self.test_folder, self.return_feats = sub_index, test_folder, return_feats
         self.video_feat_folder = video_feat_folder
         self.audio_byola_feat_folder, self.audio_emo_feat_folder = audio_byola_feat_folder, audio_emo_feat_folder
         self.feat_stride, self.num_frames, self.max_seq_len = feat_stride, num_frames, max_seq_len
@@ -218,7 +259,10 @@ class DeepFakeVideoAudioDatasetInfer3(Dataset):
         a1 = np.load(os.path.join(self.audio_byola_feat_folder, rel))[:int(self.byola_fps * it['duration'] - 0.3657)]
         a2 = np.load(os.path.join(self.audio_emo_feat_folder, rel))[:int(self.emotion_fps * it['duration'] - 0.817)]
         feat_stride = float((v.shape[0] - 1) * self.feat_stride + self.num_frames) / self.max_seq_len
-        return {'video_id': it['id'],
-                'streams': [np.ascontiguousarray(x, np.float32) for x in (v, a1, a2)], 'crop': None,
-                'fps': v.shape[0] / it['duration'], 'duration': it['duration'], 'feat_stride': feat_stride,
-                'feat_num_frames': feat_stride}
+        out = ClipItem({'video_id': it['id'],
+                        'streams': [np.ascontiguousarray(x, np.float32) for x in (v, a1, a2)], 'crop': None,
+                        'fps': v.shape[0] / it['duration'], 'duration': it['duration'], 'feat_stride': feat_stride,
+                        'feat_num_frames': feat_stride, '_max_seq_len': self.max_seq_len})
+        if self.return_feats:
+            out['feats']
+        return out

@@ -22,7 +22,16 @@ def slopes(n):
     return pow2(c) + slopes(2 * c)[0::2][: n - c]
 
 
-def alt_block(sd, p, x, heads, bias, eps):
+def alibi_bias(T, heads):
+    """get_alibi(T, heads) (upstream/models/base.py:538-604, dims=1): slopes[h] * -|i - j| -> [H, T, T].
+    Pinned: equals the reference function exactly (tests/golden/emotion2vec_parts.npz)."""
+    pos = -(torch.arange(T)[None, :] - torch.arange(T)[:, None]).abs()
+    return torch.Tensor(slopes(heads))[:, None, None] * pos[None]
+
+
+def alt_attention(sd, p, x, heads, bias):
+    """AltAttention.forward (upstream/models/modules.py:280-322; no cosine attention, no padding mask): x [B, N, C],
+    bias [H, N, N] or None.  Pinned to the reference class (tests/golden/emotion2vec_parts.npz)."""
     B, N, C = x.shape
     qkv = F.linear(x, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(B, N, 3, heads, C // heads)
     q, k, v = qkv.permute(2, 0, 3, 1, 4)
@@ -31,8 +40,12 @@ def alt_block(sd, p, x, heads, bias, eps):
         attn = attn + bias
     attn = attn.softmax(dim=-1)
     a = (attn @ v).transpose(1, 2).reshape(B, N, C)
-    a = F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
-    x = x + a
+    return F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+
+
+def alt_block(sd, p, x, heads, bias, eps):
+    B, N, C = x.shape
+    x = x + alt_attention(sd, p, x, heads, bias)
     r = x = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
     x = F.linear(F.gelu(F.linear(x, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"],
                  sd[p + "mlp.fc2.bias"])
@@ -60,8 +73,7 @@ def forward(sd, pcm, heads=12, prenet_depth=4, depth=8, eps=1e-6, conv_pos_depth
     B, T, C = x.shape
     bias_base, scale = None, None
     if a + "alibi_scale" in sd:
-        pos = -(torch.arange(T)[None, :] - torch.arange(T)[:, None]).abs().float()
-        bias_base = torch.tensor(slopes(heads))[:, None, None] * pos[None]          # [H, T, T]
+        bias_base = alibi_bias(T, heads)                                            # [H, T, T]
         scale = sd[a + "alibi_scale"].clamp_min(0)
         if scale.shape[0] == 1:
             bias_base = bias_base * scale[0, 0]

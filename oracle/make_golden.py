@@ -57,7 +57,7 @@ def ref_model(load_config, C, make_meta_arch, yaml_name, cfg):
         return ref_model_plain(load_config, C, make_meta_arch, cfg)
     rc = load_config(f"{REF}/configs_train/{yaml_name}", defaults=copy.deepcopy(C.DEFAULTS))
     m = rc["model"]
-    vdim = max(8, cfg["input_dim"] // 12)
+    vdim = cfg.get("video_dim", max(8, cfg["input_dim"] // 12))     # "video_dim": 0 = audio-only (BASELINE config 2)
     m.update(video_input_dim=vdim, audio_input_dim=cfg["input_dim"] - vdim,
              max_seq_len=cfg["max_seq_len"], embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"],
              head_dim=cfg["head_dim"], n_head=cfg["n_head"])
@@ -117,6 +117,38 @@ def yaml_for(cfg):
             "plain": "deepfake_exp10.yaml", "plainconv": "deepfake_exp10.yaml"}[cfg["variant"]]
 
 
+def eval_clips(name, model, sd, cfg, clips):
+    """`model.eval()([clip])` of the reference per clip (forward -> decode -> its C++ NMS -> seconds), the oracle's
+    `infer_clip` asserted against it, and the padded arrays a fixture stores (segments, scores, kept point index of each
+    REFERENCE segment -- taken from the oracle after the one-to-one match)."""
+    segs_all, scores_all, n_all, vc_all, kept_all = [], [], [], [], []
+    for b, clip in enumerate(clips):
+        with torch.no_grad():
+            res = model([clip])[0]
+            o = R.infer_clip(sd, cfg, clip["feats"], dict(fps=clip["fps"], duration=clip["duration"],
+                                                          feat_stride=clip["feat_stride"],
+                                                          feat_num_frames=clip["feat_num_frames"]))
+        k = res["segments"].shape[0]
+        assert o["segments"].shape[0] == k, (o["segments"].shape, k)
+        ds, dsc, perm = match_segments(res["segments"], res["scores"], o["segments"], o["scores"])
+        print(f"[{name}] clip {b}: {k} segments, oracle-vs-ref seg diff {ds:.3e} score diff {dsc:.3e} "
+              f"(rank moves among near-ties: {int((perm != torch.arange(k)).sum())})")
+        assert ds < 2e-3 and dsc < 1e-4
+        kp = np.full((cfg["max_seg_num"],), -1, np.int64)
+        kp[:k] = o["kept_points"][perm].numpy()       # point index of each REFERENCE segment
+        kept_all.append(kp)
+        pad = np.zeros((cfg["max_seg_num"], 2), np.float32)
+        pad[:k] = res["segments"].numpy()
+        sp = np.zeros((cfg["max_seg_num"],), np.float32)
+        sp[:k] = res["scores"].numpy()
+        segs_all.append(pad)
+        scores_all.append(sp)
+        n_all.append(k)
+        vc_all.append(res["video_cls"].numpy() if "video_cls" in res else np.zeros(1, np.float32))
+    return dict(segments=np.stack(segs_all), scores=np.stack(scores_all), n_segments=np.asarray(n_all),
+                video_cls=np.stack(vc_all), kept_points=np.stack(kept_all))
+
+
 def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_levels=True):
     load_config, C, make_meta_arch = ctx
     model, _ = ref_model(load_config, C, make_meta_arch, yaml_for(cfg), cfg)
@@ -147,33 +179,9 @@ def case_forward(name, cfg, lens, wseed, xseed, ctx, trained_like=True, store_le
         fpn_abs=np.array([float(f.double().abs().sum()) for f in ref["fpn"]]),
     )
     # full eval path of the reference (B=1 per clip): forward -> decode -> C++ NMS -> seconds
-    segs_all, scores_all, n_all, vc_all, kept_all = [], [], [], [], []
-    for b, n in enumerate(lens):
-        clip = dict(video_id=f"c{b}.mp4", feats=x[b, :, :n].clone(), fps=25.0, duration=n / 25.0,
-                    feat_stride=1.0, feat_num_frames=1.0)
-        with torch.no_grad():
-            res = model([clip])[0]
-            o = R.infer_clip(sd, cfg, x[b, :, :n], dict(fps=25.0, duration=n / 25.0, feat_stride=1.0,
-                                                       feat_num_frames=1.0))
-        k = res["segments"].shape[0]
-        assert o["segments"].shape[0] == k, (o["segments"].shape, k)
-        ds, dsc, perm = match_segments(res["segments"], res["scores"], o["segments"], o["scores"])
-        print(f"[{name}] clip {b}: {k} segments, oracle-vs-ref seg diff {ds:.3e} score diff {dsc:.3e} "
-              f"(rank moves among near-ties: {int((perm != torch.arange(k)).sum())})")
-        assert ds < 2e-3 and dsc < 1e-4
-        kp = np.full((cfg["max_seg_num"],), -1, np.int64)
-        kp[:k] = o["kept_points"][perm].numpy()       # point index of each REFERENCE segment
-        kept_all.append(kp)
-        pad = np.zeros((cfg["max_seg_num"], 2), np.float32)
-        pad[:k] = res["segments"].numpy()
-        sp = np.zeros((cfg["max_seg_num"],), np.float32)
-        sp[:k] = res["scores"].numpy()
-        segs_all.append(pad)
-        scores_all.append(sp)
-        n_all.append(k)
-        vc_all.append(res["video_cls"].numpy() if "video_cls" in res else np.zeros(1, np.float32))
-    out.update(segments=np.stack(segs_all), scores=np.stack(scores_all), n_segments=np.asarray(n_all),
-               video_cls=np.stack(vc_all), kept_points=np.stack(kept_all))
+    clips = [dict(video_id=f"c{b}.mp4", feats=x[b, :, :n].clone(), fps=25.0, duration=n / 25.0, feat_stride=1.0,
+                  feat_num_frames=1.0) for b, n in enumerate(lens)]
+    out.update(eval_clips(name, model, sd, cfg, clips))
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
     return model, sd, x, mask
 
@@ -511,6 +519,167 @@ def case_byola_net():
                         out=ref.numpy())
 
 
+AUDIO_EXP10 = dict(input_dim=2048, video_dim=0)                       # BASELINE config 2: BYOL-A features only, exp10 architecture
+EXP5 = dict(variant="recon", input_dim=1024, video_dim=256)           # BASELINE config 1: deepfake_exp5.yaml at full size
+
+
+def case_tinydataset(ctx):
+    """BASELINE config 1: the reference's `tinydataset/metadata/**.json` (12 files) -> its `deepfake_video_audio` dataset
+    class (libs/datasets/deepfake_video_audio.py:739-1102) on seeded synthetic features of the extractors' shapes -> its
+    exp5 model (`AVLocPointTransformerRecoveryNoNorm`, full size, seeded weights) in eval mode, one clip per call like
+    inference.py.  Stores the metadata fields the datasets read (data), per-item checksums / segments and the detections."""
+    import glob
+    import json
+    import random
+    import tempfile
+    from oracle.synth_data import TINY_FIELDS, tiny_tree_from_fixture, tiny_dataset_kwargs
+    from libs.datasets import make_dataset
+    load_config, C, make_meta_arch = ctx
+    metas = []
+    for f in sorted(glob.glob(f"{REF}/tinydataset/metadata/**/*.json", recursive=True)):
+        v = json.load(open(f))
+        assert v["file"].replace(".mp4", ".json") == os.path.relpath(f, f"{REF}/tinydataset/metadata")
+        metas.append({k: v[k] for k in TINY_FIELDS})
+    assert len(metas) == 12
+    fixture = os.path.join(GOLD, "tinydataset_meta.json")
+    with open(fixture, "w") as f:
+        json.dump(metas, f, indent=0)
+    root = tempfile.mkdtemp(prefix="avdf_tiny_")
+    rels = tiny_tree_from_fixture(root, fixture, seed=500)
+    kw = tiny_dataset_kwargs(root)
+    kw_ref = dict(kw, json_folder=f"{REF}/tinydataset/metadata")           # the reference reads its OWN files
+    out = {"n": len(rels), "wseed": 71}
+    cfg = R.make_cfg(**EXP5)
+    model, _ = ref_model(load_config, C, make_meta_arch, "deepfake_exp5.yaml", cfg)
+    sd = R.synth_state_dict(R.param_shapes(cfg), 71, True)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    ds_eval = make_dataset("deepfake_video_audio", False, ["train"], **kw_ref)
+    ds_train = make_dataset("deepfake_video_audio", True, ["train"], **kw_ref)
+    clips = []
+    for i in range(len(ds_eval)):
+        d = ds_eval[i]
+        f = d["feats"]
+        assert tuple(f.shape) == (1024, 768)
+        out[f"e{i}_sum"] = np.array([float(f.double().sum()), float(f.double().abs().sum())])
+        out[f"e{i}_row0"], out[f"e{i}_rowN"] = f[0].numpy(), f[-1].numpy()
+        out[f"e{i}_segments"] = np.zeros((0, 2), np.float32) if d["segments"] is None else d["segments"].numpy()
+        out[f"e{i}_meta"] = np.array([d["fps"], d["duration"], d["feat_stride"], d["feat_num_frames"]], np.float64)
+        out[f"e{i}_av"] = d["av_labels"].numpy()
+        clips.append(d)
+        random.seed(900 + i)
+        t = ds_train[i]
+        ft = t["feats"]
+        out[f"t{i}_shape"] = np.array(ft.shape)
+        out[f"t{i}_sum"] = np.array([float(ft.double().sum()), float(ft.double().abs().sum())])
+        out[f"t{i}_segments"] = np.zeros((0, 2), np.float32) if t["segments"] is None else t["segments"].numpy()
+    out.update(eval_clips("tinydataset", model, sd, cfg, clips))
+    np.savez_compressed(os.path.join(GOLD, "tinydataset.npz"), **out)
+    print("[tinydataset] stored", len(rels), "items; segments per clip:", out["n_segments"].tolist())
+
+
+def case_optimizer_split(ctx):
+    """make_optimizer's decay / no-decay partition (libs/utils/train_utils.py:65-122) of the three shipped models: counts
+    and a digest of the sorted decayed names (exp10 = 195 decayed / 413 not)."""
+    import hashlib
+    from libs.utils.train_utils import make_optimizer
+    load_config, C, make_meta_arch = ctx
+    out = {}
+    for tag, yaml_name in (("exp10", "deepfake_exp10.yaml"), ("exp5", "deepfake_exp5.yaml"), ("exp13", "deepfake_exp13.yaml")):
+        rc = load_config(f"{REF}/configs_train/{yaml_name}", defaults=copy.deepcopy(C.DEFAULTS))
+        model = make_meta_arch(rc["model_name"], **rc["model"])
+        opt = make_optimizer(model, rc["opt"])
+        names = {id(p): n for n, p in model.named_parameters()}
+        decay = sorted(names[id(p)] for p in opt.param_groups[0]["params"])
+        no_decay = sorted(names[id(p)] for p in opt.param_groups[1]["params"])
+        assert opt.param_groups[1]["weight_decay"] == 0.0
+        out[f"{tag}_counts"] = np.array([len(decay), len(no_decay)])
+        out[f"{tag}_decay_sha"] = np.array(hashlib.sha256("\n".join(decay).encode()).hexdigest())
+        out[f"{tag}_nodecay_sha"] = np.array(hashlib.sha256("\n".join(no_decay).encode()).hexdigest())
+        out[f"{tag}_hparams"] = np.array([opt.param_groups[0]["weight_decay"], opt.param_groups[0]["lr"]])
+        print(f"[optimizer_split] {tag}: {len(decay)} decayed / {len(no_decay)} not")
+    assert tuple(out["exp10_counts"]) == (195, 413)
+    np.savez_compressed(os.path.join(GOLD, "optimizer_split.npz"), **out)
+
+
+def import_emotion2vec_torch_only():
+    """upstream/models/{modules,base}.py of audio_feature/emotion_audio imported by path into a synthetic package.
+    Names they import at module level from packages that are absent here -- and that the functions pinned below NEVER
+    execute -- are stubbed: fairseq.modules.{LayerNorm, SamePad, TransposeLast, GradMultiply},
+    fairseq.data.data_utils.compute_mask_indices, fairseq.utils.index_put, omegaconf.{MISSING, II} (dataclass field
+    defaults).  Executed for the fixtures: get_alibi, get_alibi_bias (base.py:538-642) and AltAttention (modules.py:252-322),
+    all torch-only.  AltBlock stays unpinned: its constructor takes Mlp / DropPath from timm, which would be executed."""
+    import importlib.util
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    unused = type("NeverExecuted", (), {})
+    stub("fairseq")
+    stub("fairseq.modules", LayerNorm=unused, SamePad=unused, TransposeLast=unused, GradMultiply=unused)
+    stub("fairseq.data")
+    stub("fairseq.data.data_utils", compute_mask_indices=unused)
+    stub("fairseq.utils", index_put=unused)
+    stub("omegaconf", MISSING="???", II=lambda s: s)
+    root = os.path.join(REF, "audio_feature", "emotion_audio", "upstream", "models")
+    pkg = types.ModuleType("e2v_upstream_models")
+    pkg.__path__ = [root]
+    sys.modules["e2v_upstream_models"] = pkg
+    mods = {}
+    for name in ("modules", "base"):
+        spec = importlib.util.spec_from_file_location(f"e2v_upstream_models.{name}", os.path.join(root, f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"e2v_upstream_models.{name}"] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods["modules"], mods["base"]
+
+
+def case_emotion2vec_parts():
+    """ALiBi bias + attention of Emotion2Vec pinned to the reference's own torch-only code (see the import helper)."""
+    from oracle import emotion2vec_ref as ER
+    sys.dont_write_bytecode = True
+    M, Bm = import_emotion2vec_torch_only()
+    out = {}
+    for heads, T in ((12, 33), (8, 17), (6, 9)):
+        ref = Bm.get_alibi(T, heads)
+        mine = ER.alibi_bias(T, heads)
+        assert torch.equal(ref, mine), (heads, T)
+        out[f"alibi_h{heads}_t{T}"] = ref.numpy()
+    cache = {}
+    b = Bm.get_alibi_bias(cache, batch_size=2, time_steps=21, heads=12, dtype=torch.float32, device=torch.device("cpu"))
+    assert b.shape == (2, 12, 21, 21) and torch.equal(b[0], ER.alibi_bias(21, 12)) and torch.equal(b[1], b[0])
+    b2 = Bm.get_alibi_bias(cache, batch_size=1, time_steps=13, heads=12, dtype=torch.float32, device=torch.device("cpu"))
+    assert torch.equal(b2[0], ER.alibi_bias(13, 12))             # served from the cached, larger table
+    out["alibi_bias_b2_t21"] = b.numpy()
+    # AltAttention at the model's real width (768, 12 heads), seeded weights and input, with a per-head scaled ALiBi bias
+    dim, heads, N, wseed, xseed = 768, 12, 57, 8101, 8102
+    rs = np.random.RandomState(wseed)
+    attn = M.AltAttention(dim, num_heads=heads, qkv_bias=True).eval()
+    sd = {"qkv.weight": rs.uniform(-1, 1, (3 * dim, dim)) / np.sqrt(dim) * 2.0, "qkv.bias": 0.1 * rs.standard_normal(3 * dim),
+          "proj.weight": rs.uniform(-1, 1, (dim, dim)) / np.sqrt(dim), "proj.bias": 0.1 * rs.standard_normal(dim)}
+    sd = {k: torch.from_numpy(v.astype(np.float32)) for k, v in sd.items()}
+    attn.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(np.random.RandomState(xseed).standard_normal((2, N, dim)).astype(np.float32))
+    scale = torch.from_numpy((0.5 + rs.uniform(0, 1, heads)).astype(np.float32)).view(1, heads, 1, 1)
+    bias = Bm.get_alibi_bias({}, 2, N, heads, torch.float32, torch.device("cpu")) * scale
+    with torch.no_grad():
+        ref_b = attn(x, None, bias.clone())
+        ref_n = attn(x, None, None)
+        mine_b = ER.alt_attention({"attn." + k: v for k, v in sd.items()}, "", x, heads, bias[0])
+        mine_n = ER.alt_attention({"attn." + k: v for k, v in sd.items()}, "", x, heads, None)
+    e1, e2 = maxdiff(ref_b, mine_b), maxdiff(ref_n, mine_n)
+    print(f"[emotion2vec_parts] AltAttention oracle vs reference: with alibi {e1:.2e}, without {e2:.2e}")
+    assert e1 < 2e-6 and e2 < 2e-6
+    out.update(attn_wseed=wseed, attn_xseed=xseed, attn_shape=np.array([2, N, dim, heads]), attn_scale=scale.view(-1).numpy(),
+               attn_out_alibi=ref_b.numpy(), attn_out_plain=ref_n.numpy())
+    np.savez_compressed(os.path.join(GOLD, "emotion2vec_parts.npz"), **out)
+
+
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -522,6 +691,13 @@ def main():
     case_metrics()
     case_lr_schedules()
     case_byola_net()
+    case_emotion2vec_parts()
+    case_optimizer_split(ctx)
+    case_tinydataset(ctx)
+    case_forward("fwd_audio_exp10", R.make_cfg(**AUDIO_EXP10), [768, 601], 81, 82, ctx)
+    case_train("train_audio_exp10", R.make_cfg(**AUDIO_EXP10), [768, 700, 768, 650], 81, 83, ctx)
+    case_forward("fwd_exp5", R.make_cfg(**EXP5), [768, 655], 91, 92, ctx)
+    case_train("train_exp5", R.make_cfg(**EXP5), [768, 700, 640], 91, 93, ctx)
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
     case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
     case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)
@@ -540,37 +716,32 @@ def main():
     print("done")
 
 
+NAMED = {
+    "metrics": lambda ctx: case_metrics(),
+    "nms_modes": lambda ctx: case_nms_modes(),
+    "lr": lambda ctx: case_lr_schedules(),
+    "byola_net": lambda ctx: case_byola_net(),
+    "emotion2vec_parts": lambda ctx: case_emotion2vec_parts(),
+    "optimizer_split": case_optimizer_split,
+    "tinydataset": case_tinydataset,
+    "train_exp10": lambda ctx: case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, ctx),
+    "audio_exp10": lambda ctx: (case_forward("fwd_audio_exp10", R.make_cfg(**AUDIO_EXP10), [768, 601], 81, 82, ctx),
+                                case_train("train_audio_exp10", R.make_cfg(**AUDIO_EXP10), [768, 700, 768, 650], 81, 83, ctx)),
+    "exp5": lambda ctx: (case_forward("fwd_exp5", R.make_cfg(**EXP5), [768, 655], 91, 92, ctx),
+                         case_train("train_exp5", R.make_cfg(**EXP5), [768, 700, 640], 91, 93, ctx)),
+    "plainconv": lambda ctx: (case_forward("fwd_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 133], 61, 62, ctx),
+                              case_train("train_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 150, 180, 192], 63, 64, ctx)),
+    "plain": lambda ctx: (case_forward("fwd_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 151], 51, 52, ctx),
+                          case_train("train_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 150, 180, 192], 53, 54, ctx)),
+}
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "metrics":         # regenerate one fixture without the model cases
-        os.makedirs(GOLD, exist_ok=True)
-        import_reference()
-        case_metrics()
-    elif len(sys.argv) > 1 and sys.argv[1] == "train_exp10":
-        os.makedirs(GOLD, exist_ok=True)
-        torch.set_num_threads(8)
-        case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, import_reference())
-    elif len(sys.argv) > 1 and sys.argv[1] == "plainconv":
-        os.makedirs(GOLD, exist_ok=True)
-        torch.set_num_threads(8)
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    if len(sys.argv) > 1:                        # regenerate the named fixtures only
         ctx = import_reference()
-        case_forward("fwd_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 133], 61, 62, ctx)
-        case_train("train_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 150, 180, 192], 63, 64, ctx)
-    elif len(sys.argv) > 1 and sys.argv[1] == "plain":
-        os.makedirs(GOLD, exist_ok=True)
-        torch.set_num_threads(8)
-        ctx = import_reference()
-        case_forward("fwd_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 151], 51, 52, ctx)
-        case_train("train_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 150, 180, 192], 53, 54, ctx)
-    elif len(sys.argv) > 1 and sys.argv[1] == "nms_modes":
-        os.makedirs(GOLD, exist_ok=True)
-        import_reference()
-        case_nms_modes()
-    elif len(sys.argv) > 1 and sys.argv[1] == "byola_net":
-        os.makedirs(GOLD, exist_ok=True)
-        case_byola_net()
-    elif len(sys.argv) > 1 and sys.argv[1] == "lr":
-        os.makedirs(GOLD, exist_ok=True)
-        import_reference()
-        case_lr_schedules()
+        for nm in sys.argv[1:]:
+            NAMED[nm](ctx)
     else:
         main()

@@ -85,3 +85,35 @@ def test_loader_yields_lists_of_dicts(tmp_path):
     loader = D.make_data_loader(ds, True, torch.Generator().manual_seed(0), batch_size=2, num_workers=0)
     batch = next(iter(loader))
     assert isinstance(batch, list) and len(batch) == 2 and "streams" in batch[0]
+
+
+def test_tinydataset_metadata_items_match_reference(tmp_path, golden_dir):
+    """The reference's own 12 `tinydataset/metadata/**.json` files (tests/golden/tinydataset_meta.json keeps the fields the
+    dataset classes read) through the `deepfake_video_audio` (exp5) dataset plugin: metadata, grid-unit segments, the
+    seeded training crop and the resampled feature matrix equal the reference class's items (libs/datasets/
+    deepfake_video_audio.py:739-1102) on the same seeded feature files."""
+    from oracle.synth_data import tiny_tree_from_fixture, tiny_dataset_kwargs
+    g = np.load(os.path.join(golden_dir, "tinydataset.npz"), allow_pickle=True)
+    D = _load_datasets_module()
+    root = str(tmp_path)
+    tiny_tree_from_fixture(root, os.path.join(golden_dir, "tinydataset_meta.json"), seed=500)
+    kw = tiny_dataset_kwargs(root)
+    ds_eval = D.make_dataset("deepfake_video_audio", False, ["train"], **kw)
+    ds_train = D.make_dataset("deepfake_video_audio", True, ["train"], **kw)
+    assert len(ds_eval) == int(g["n"]) == 12
+    for i in range(12):
+        d = ds_eval[i]
+        f = R.interp_concat(d["streams"], 768)
+        assert tuple(f.shape) == (1024, 768)
+        assert np.allclose([float(f.double().sum()), float(f.double().abs().sum())], g[f"e{i}_sum"], rtol=1e-9)
+        seg = np.zeros((0, 2), np.float32) if d["segments"] is None else d["segments"].numpy()
+        assert np.array_equal(seg, g[f"e{i}_segments"])
+        assert np.array_equal(np.array([d["fps"], d["duration"], d["feat_stride"], d["feat_num_frames"]], np.float64), g[f"e{i}_meta"])
+        assert np.array_equal(d["av_labels"].numpy(), g[f"e{i}_av"])
+        random.seed(900 + i)
+        t = ds_train[i]
+        ft = _feats(t)
+        assert tuple(ft.shape) == tuple(g[f"t{i}_shape"])
+        assert np.allclose([float(ft.double().sum()), float(ft.double().abs().sum())], g[f"t{i}_sum"], rtol=1e-9)
+        segt = np.zeros((0, 2), np.float32) if t["segments"] is None else t["segments"].numpy()
+        assert np.array_equal(segt, g[f"t{i}_segments"])

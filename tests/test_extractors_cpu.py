@@ -50,3 +50,36 @@ def test_byola_oracle_matches_reference_network(golden_dir):
     m = AudioNTT2020Task6(64, 2048)
     assert set(m.state_dict().keys()) == set(sd.keys())
     m.load_state_dict(sd, strict=True)
+
+
+def test_emotion2vec_alibi_and_attention_oracle_match_reference(golden_dir):
+    """oracle/emotion2vec_ref.{alibi_bias, alt_attention} == the reference's own get_alibi / get_alibi_bias / AltAttention
+    (upstream/models/base.py:538-642, modules.py:252-322), executed by oracle/make_golden.py emotion2vec_parts."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "emotion2vec_parts.npz"))
+    for heads, T in ((12, 33), (8, 17), (6, 9)):
+        assert np.array_equal(R.alibi_bias(T, heads).numpy(), g[f"alibi_h{heads}_t{T}"])
+    assert np.array_equal(R.alibi_bias(21, 12).numpy(), g["alibi_bias_b2_t21"][1])
+    B, N, dim, heads = [int(v) for v in g["attn_shape"]]
+    sd, x, scale = attn_fixture_inputs(g)
+    bias = R.alibi_bias(N, heads) * scale.view(heads, 1, 1)
+    out_b = R.alt_attention(sd, "", x, heads, bias)
+    out_n = R.alt_attention(sd, "", x, heads, None)
+    assert float((out_b - torch.from_numpy(g["attn_out_alibi"])).abs().max()) < 2e-6
+    assert float((out_n - torch.from_numpy(g["attn_out_plain"])).abs().max()) < 2e-6
+
+
+def attn_fixture_inputs(g):
+    """Seeded AltAttention weights / input / per-head ALiBi scale of tests/golden/emotion2vec_parts.npz (same draws, in the
+    same order, as oracle/make_golden.py case_emotion2vec_parts)."""
+    import numpy as np
+    B, N, dim, heads = [int(v) for v in g["attn_shape"]]
+    rs = np.random.RandomState(int(g["attn_wseed"]))
+    sd = {"attn.qkv.weight": rs.uniform(-1, 1, (3 * dim, dim)) / np.sqrt(dim) * 2.0, "attn.qkv.bias": 0.1 * rs.standard_normal(3 * dim),
+          "attn.proj.weight": rs.uniform(-1, 1, (dim, dim)) / np.sqrt(dim), "attn.proj.bias": 0.1 * rs.standard_normal(dim)}
+    sd = {k: torch.from_numpy(v.astype(np.float32)) for k, v in sd.items()}
+    x = torch.from_numpy(np.random.RandomState(int(g["attn_xseed"])).standard_normal((B, N, dim)).astype(np.float32))
+    scale = torch.from_numpy((0.5 + rs.uniform(0, 1, heads)).astype(np.float32))
+    assert np.array_equal(scale.numpy(), g["attn_scale"])
+    return sd, x, scale

@@ -25,7 +25,9 @@ def synth_inputs(cfg, lens, seed):
                                        ("fwd_the_small", dict(variant="the", **SMALL)),
                                        ("fwd_recon_small", dict(variant="recon", **SMALL)),
                                        ("fwd_plain_small", dict(variant="plain", **SMALL)),
-                                       ("fwd_conv_small", dict(variant="plainconv", **SMALL)), ("fwd_exp10", {})])
+                                       ("fwd_conv_small", dict(variant="plainconv", **SMALL)), ("fwd_exp10", {}),
+                                       ("fwd_audio_exp10", dict(input_dim=2048, video_dim=0)),                   # BASELINE config 2
+                                       ("fwd_exp5", dict(variant="recon", input_dim=1024, video_dim=256))])     # BASELINE config 1
 def test_oracle_forward_and_detections_match_reference(golden_dir, name, over):
     torch.set_num_threads(8)
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
@@ -103,3 +105,33 @@ def test_oracle_nms_matches_reference_native_op(golden_dir):
         ref = g[f"keep{i}"]
         assert sorted(keep.tolist()) == sorted(ref.tolist()), f"nms case {i}"
         assert np.array_equal(sc[keep], sc[ref]), f"nms case {i}: score order"
+
+
+def test_oracle_on_tinydataset_items_matches_reference(tmp_path, golden_dir):
+    """BASELINE config 1 on the CPU: the reference's 12 tinydataset metadata files -> the dataset plugin's raw streams ->
+    oracle K1 + oracle exp5 model == what the reference's own dataset class + model produced (tests/golden/tinydataset.npz).
+    Three clips keep the CPU suite short; the GPU test covers all 12 through the product path."""
+    from oracle.synth_data import tiny_tree_from_fixture, tiny_dataset_kwargs
+    from tests.test_datasets_cpu import _load_datasets_module
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "tinydataset.npz"), allow_pickle=True)
+    D = _load_datasets_module()
+    root = str(tmp_path)
+    tiny_tree_from_fixture(root, os.path.join(golden_dir, "tinydataset_meta.json"), seed=500)
+    ds = D.make_dataset("deepfake_video_audio", False, ["train"], **tiny_dataset_kwargs(root))
+    cfg = R.make_cfg(variant="recon", input_dim=1024, video_dim=256)
+    sd = R.synth_state_dict(R.param_shapes(cfg), int(g["wseed"]), True)
+    for i in (0, 5, 11):
+        d = ds[i]
+        f = R.interp_concat(d["streams"], 768)
+        assert np.array_equal(f[0].numpy(), g[f"e{i}_row0"]) and np.array_equal(f[-1].numpy(), g[f"e{i}_rowN"])
+        meta = dict(fps=d["fps"], duration=d["duration"], feat_stride=d["feat_stride"], feat_num_frames=d["feat_num_frames"])
+        assert np.array_equal(np.array(list(meta.values()), np.float64), g[f"e{i}_meta"])
+        o = R.infer_clip(sd, cfg, f, meta)
+        k = int(g["n_segments"][i])
+        ref_pts = g["kept_points"][i][:k]
+        assert sorted(o["kept_points"].tolist()) == sorted(ref_pts.tolist())
+        order = {int(p): j for j, p in enumerate(o["kept_points"].tolist())}
+        perm = torch.tensor([order[int(p)] for p in ref_pts], dtype=torch.int64)
+        assert float((o["segments"][perm] - torch.from_numpy(g["segments"][i][:k])).abs().max()) < 1e-4
+        assert float((o["scores"][perm] - torch.from_numpy(g["scores"][i][:k])).abs().max()) < 1e-5
