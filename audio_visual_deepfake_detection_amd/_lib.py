@@ -58,6 +58,8 @@ SIGNATURES = {
     "avdf_masked_colsum": (I, [P, P, P, P, L, I, I, P]),
     "avdf_l1_mean_ws": (L, []),
     "avdf_l1_mean": (I, [P, P, P, P, P, P, I, L, F, P]),
+    "avdf_count_real": (I, [P, P, I, P]),
+    "avdf_l1_mean_dev": (I, [P, P, P, P, P, P, P, P, I, L, P]),
     "avdf_scale_rows": (I, [P, P, P, I, I, P]),
     "avdf_transpose": (I, [P, P, I, I, I, P]),
     "avdf_instnorm_lrelu_fwd": (I, [P, P, P, P, I, I, I, F, F, P]),
@@ -103,6 +105,8 @@ SIGNATURES = {
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
     "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),
+    "avdf_adamw_ema_seg": (I, [P, P, P, P, P, P, P, L, I, P, P, F, F, F, F, F, I, P]),
+    "avdf_sumsq_ex": (I, [P, P, P, L, I, P]),
 }
 
 

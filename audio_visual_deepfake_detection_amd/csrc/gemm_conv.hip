@@ -877,7 +877,9 @@ inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, 
 }
 // GEMM arithmetic mode: 0 = exact fp32 MFMA (default, what the parity goldens are held against), 1 = split-bf16
 // ("bf16x3") operands in the forward kernels (experimental, avdf_gemm_mode)
-static int g_gemm_mode = [] { const char* e = getenv("AVDF_GEMM_MODE"); return e ? atoi(e) : 0; }();
+// thread-local: the mode is a launch-time host switch, so a thread that runs inference in bf16x3 cannot change the
+// arithmetic of a training thread that shares the library
+static thread_local int g_gemm_mode = [] { const char* e = getenv("AVDF_GEMM_MODE"); return e ? atoi(e) : 0; }();
 // process-wide override used by the tuner: g_override[kind] = {a, b}, -1 = off
 static int g_override[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};   // [3] unused, [4] = backward pair
 
@@ -1425,7 +1427,7 @@ extern "C" int avdf_gemm_override(int kind, int a, int b) {
   return AVDF_OK;
 }
 
-// 0 = exact fp32 MFMA (default); 1 = split-bf16 (bf16x3) operands in the forward conv GEMMs (experimental)
+// 0 = exact fp32 MFMA (default); 1 = split-bf16 (bf16x3) operands in the forward conv GEMMs.  Per calling thread.
 extern "C" int avdf_gemm_mode(int mode) {
   AVDF_REQUIRE(mode == 0 || mode == 1, "gemm_mode: 0 (fp32) or 1 (bf16x3 forward)");
   g_gemm_mode = mode;

@@ -214,9 +214,71 @@ __global__ void l1_final_kernel(const float* __restrict__ partial, int n, float*
   out[0] = s * inv_denom;
 }
 
+// engine variants: the set of real clips (ngt == 0) and the GLOBAL number of real clips are device data, so the launch
+// can sit in a captured graph and the count can be all-reduced across data-parallel ranks first
+__global__ void count_real_kernel(const int32_t* __restrict__ ngt, int B, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0;
+  for (int b = 0; b < B; ++b) n += (ngt[b] == 0);
+  out[0] = (float)n;
+}
+
+__global__ __launch_bounds__(256) void l1_dev_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const int32_t* __restrict__ ngt, const float* __restrict__ n_real,
+                                                     float* __restrict__ partial, float* __restrict__ da, int B, long per) {
+  __shared__ float red[256];
+  float s = 0.f;
+  const long total = (long)B * per;
+  const float inv_denom = 1.f / (n_real[0] * (float)per);          // n_real == 0: inf * 0 = nan, like torch.mean of nothing
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float w_ = ngt[i / per] == 0 ? 1.f : 0.f;
+    const float d = a[i] - b[i];
+    s += w_ * fabsf(d);
+    if (da) da[i] = w_ == 0.f ? 0.f : inv_denom * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void l1_dev_final_kernel(const float* __restrict__ partial, int n, const float* __restrict__ n_real, long per,
+                                    float* __restrict__ out, float* __restrict__ final_loss) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += partial[i];
+  const float v = n_real[0] > 0.f ? s / (n_real[0] * (float)per) : nanf("");
+  out[0] = v;
+  if (final_loss) final_loss[0] += v;
+}
+
 }  // namespace
 
 constexpr int kL1Blocks = 512;
+
+extern "C" int avdf_count_real(const int32_t* ngt, float* out, int B, void* stream) {
+  AVDF_REQUIRE(ngt && out && B > 0, "count_real: bad args");
+  hipLaunchKernelGGL(count_real_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ngt, B, out);
+  AVDF_CHECK_LAUNCH("count_real");
+  return AVDF_OK;
+}
+
+// exp5 reconstruction loss inside the captured engine step: real clips = {b : ngt[b] == 0}; n_real = device float[1], the
+// number of real clips of the GLOBAL batch (all-reduced by the caller); out[0] = this rank's share of the mean, added to
+// final_loss[0] when given; da = d(out)/da
+extern "C" int avdf_l1_mean_dev(const float* a, const float* b, const int32_t* ngt, const float* n_real, float* out,
+                                float* final_loss, float* da, float* ws, int B, int64_t per_clip, void* stream) {
+  AVDF_REQUIRE(a && b && ngt && n_real && out && ws && B > 0 && per_clip > 0, "l1_mean_dev: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_dev_kernel, dim3(kL1Blocks), dim3(256), 0, st, a, b, ngt, n_real, ws, da, B, (long)per_clip);
+  hipLaunchKernelGGL(l1_dev_final_kernel, dim3(1), dim3(64), 0, st, ws, kL1Blocks, n_real, (long)per_clip, out, final_loss);
+  AVDF_CHECK_LAUNCH("l1_mean_dev");
+  return AVDF_OK;
+}
+
 extern "C" int64_t avdf_l1_mean_ws(void) { return kL1Blocks; }
 
 // L1 reconstruction loss of exp5 on the REAL clips only (av_fd_meta_arch.py:683-686):

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out, int accumulate) {
   __shared__ float red[256];
   float s = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
@@ -28,7 +28,7 @@ __global__ void sumsq_final_kernel(const float* __restrict__ partial, int nb, fl
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] += red[0];
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0];
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -59,20 +59,53 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
 }
 
 constexpr int kSumsqBlocks = 1024;
+constexpr int kMaxSeg = 8;
+struct WdSegments { int64_t end[kMaxSeg]; float wd[kMaxSeg]; int n; };
+
+// the same update over a flat buffer made of up to kMaxSeg consecutive [.., end) ranges with their own weight decay
+// (engine.TrainStep: gradient buckets x {decayed, not decayed}): one launch per step instead of one per range
+__global__ __launch_bounds__(256) void adamw_ema_seg_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
+                                                            const float* __restrict__ gnorm_sq, const float* __restrict__ hp,
+                                                            int64_t n, WdSegments seg, float beta1, float beta2, float eps,
+                                                            float clip_norm, float ema_decay, float* __restrict__ g_zero) {
+  const float lr = hp[0], bias_c1 = hp[1], bias_c2 = hp[2];
+  float cs = 1.f;
+  if (gnorm_sq && clip_norm > 0.f) cs = fminf(clip_norm / (sqrtf(gnorm_sq[0]) + 1e-6f), 1.f);
+  const float step = lr / bias_c1;
+  const float inv_sqrt_c2 = 1.f / sqrtf(bias_c2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float wd = seg.wd[seg.n - 1];
+    for (int s_ = 0; s_ < seg.n; ++s_) if (i < seg.end[s_]) { wd = seg.wd[s_]; break; }
+    const float gi = g[i] * cs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) * inv_sqrt_c2 + eps);
+    p[i] = pi;
+    if (ema) ema[i] = ema[i] * ema_decay + (1.f - ema_decay) * pi;
+    if (g_zero) g_zero[i] = 0.f;      // the consumed gradient is cleared here: the next backward accumulates into zeros
+  }
+}
 
 }  // namespace
 
 extern "C" int64_t avdf_sumsq_ws(void) { return kSumsqBlocks; }
 
-extern "C" int avdf_sumsq(const float* x, float* out, float* ws, int64_t n, void* stream) {
+extern "C" int avdf_sumsq_ex(const float* x, float* out, float* ws, int64_t n, int accumulate, void* stream) {
   AVDF_REQUIRE(x && out && ws && n > 0, "sumsq: bad args");
   hipStream_t st = (hipStream_t)stream;
   int64_t nb = (n + 255) / 256;
   if (nb > kSumsqBlocks) nb = kSumsqBlocks;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ws, n);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, ws, (int)nb, out, accumulate);
   AVDF_CHECK_LAUNCH("sumsq");
   return AVDF_OK;
+}
+
+extern "C" int avdf_sumsq(const float* x, float* out, float* ws, int64_t n, void* stream) {
+  return avdf_sumsq_ex(x, out, ws, n, 1, stream);
 }
 
 extern "C" int avdf_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
@@ -84,5 +117,29 @@ extern "C" int avdf_adamw_ema(float* p, const float* g, float* m, float* v, floa
   hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, gnorm_sq, hp, n,
                      beta1, beta2, eps, wd, clip_norm, ema_decay);
   AVDF_CHECK_LAUNCH("adamw_ema");
+  return AVDF_OK;
+}
+
+// nseg consecutive ranges [seg_end[i-1], seg_end[i]) (seg_end[nseg-1] == n) with weight decay seg_wd[i]: HOST arrays
+extern "C" int avdf_adamw_ema_seg(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
+                                  const float* hp, int64_t n, int nseg, const int64_t* seg_end, const float* seg_wd,
+                                  float beta1, float beta2, float eps, float clip_norm, float ema_decay, int zero_grad,
+                                  void* stream) {
+  AVDF_REQUIRE(p && g && m && v && hp && n > 0 && seg_end && seg_wd, "adamw_ema_seg: bad args");
+  AVDF_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "adamw_ema_seg: 1..%d segments", kMaxSeg);
+  WdSegments seg;
+  seg.n = nseg;
+  int64_t prev = 0;
+  for (int i = 0; i < nseg; ++i) {
+    AVDF_REQUIRE(seg_end[i] >= prev, "adamw_ema_seg: segment ends must be non-decreasing");
+    seg.end[i] = prev = seg_end[i];
+    seg.wd[i] = seg_wd[i];
+  }
+  AVDF_REQUIRE(prev == n, "adamw_ema_seg: the last segment must end at n");
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(adamw_ema_seg_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, gnorm_sq, hp,
+                     n, seg, beta1, beta2, eps, clip_norm, ema_decay, zero_grad ? const_cast<float*>(g) : (float*)nullptr);
+  AVDF_CHECK_LAUNCH("adamw_ema_seg");
   return AVDF_OK;
 }

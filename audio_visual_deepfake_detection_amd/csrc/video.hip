@@ -284,7 +284,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-static int g_c3d_mode = 0;      // 0 exact fp32 MFMA, 1 split-bf16 operands (layers with Cin >= 16)
+static thread_local int g_c3d_mode = 0;      // 0 exact fp32 MFMA, 1 split-bf16 operands (layers with Cin >= 16); per calling thread
 static int g_c3d_n96_small = [] { const char* e = getenv("AVDF_C3D_N96_SMALL"); return e ? atoi(e) : 1; }();
 extern "C" int avdf_conv3d_mode(int mode) {
   AVDF_REQUIRE(mode == 0 || mode == 1, "conv3d_mode: 0 (fp32) or 1 (bf16x3)");

@@ -162,9 +162,24 @@ class AudioNTT2020Task6(nn.Module):
 
 
 @torch.no_grad()
-def byola_features(pcm, model, frontend):
+def byola_features(pcm, model, frontend, pad_frames=None):
     """PCM [N] fp32 @16 kHz (device) -> [(1 + N // 160) // 8, 2048], the array the reference saves as .npy
-    (extract_audio_feature_batch.py:104-123) before the dataset trims it (deepfake_video_audio.py:1683)."""
+    (extract_audio_feature_batch.py:104-123) before the dataset trims it (deepfake_video_audio.py:1683).
+    pad_frames: log-mel length the clip is zero-padded to before the network (see `byola_features_batch`)."""
     lms = frontend(pcm)                      # STFT / mel GEMMs stay exact fp32: log() follows
+    if pad_frames is not None and pad_frames > lms.shape[1]:
+        lms = torch.nn.functional.pad(lms, (0, pad_frames - lms.shape[1]))          # zeros AFTER normalisation
     with ops.infer_mode():
         return model.forward_image(lms)
+
+
+@torch.no_grad()
+def byola_features_batch(pcms, model, frontend):
+    """The reference's batch semantics (extract_audio_feature_batch.py:65-81,111-123): the NORMALISED log-mels of a batch
+    are zero-padded to the longest one (post-normalisation zeros, i.e. not silence), the network runs on the padded
+    images and every clip's feature array is saved UNTRIMMED ([max_frames // 8, 2048]; the dataset trims at load time,
+    deepfake_video_audio.py:1683).  The network has no cross-clip operator (BatchNorm in eval mode), so clip i of the
+    padded batch is the per-clip forward of its padded image; the rows of a shorter clip near and beyond its end differ
+    from `byola_features(pcm)` because the 3x3 convs see relu(bn(0)) activations where the un-padded image ends."""
+    frames = max(1 + int(p.numel()) // HOP for p in pcms)
+    return [byola_features(p, model, frontend, pad_frames=frames) for p in pcms]

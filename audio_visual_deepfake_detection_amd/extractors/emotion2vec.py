@@ -230,9 +230,22 @@ class Emotion2Vec(nn.Module):
 
 
 @torch.no_grad()
-def emotion2vec_features(pcm, model, n_samples=None):
+def emotion2vec_features(pcm, model, n_samples=None, pad_samples=None):
     """PCM [N] -> the array the reference saves (scripts/extract_audio_feature_batch.py:85-98):
-    feats['x'][: int(50 * len - 0.817)] with len in seconds."""
-    x = model.forward_clip(pcm)
+    feats['x'][: int(50 * len - 0.817)] with len in seconds.  pad_samples: waveform length the clip is zero-padded to
+    before the encoder (see `emotion2vec_features_batch`)."""
     n = pcm.numel() if n_samples is None else n_samples
+    if pad_samples is not None and pad_samples > pcm.numel():
+        pcm = torch.nn.functional.pad(pcm, (0, pad_samples - pcm.numel()))
+    x = model.forward_clip(pcm)
     return x[:int(50 * (n / 16000.0) - 0.817)]
+
+
+@torch.no_grad()
+def emotion2vec_features_batch(pcms, model):
+    """The reference's batch semantics (scripts/extract_audio_feature_batch.py:35-52,73-91): waveforms zero-padded to the
+    longest of the batch, `extract_features(wav, padding_mask=None)` -- so the attention of a shorter clip also attends to
+    its padding positions -- then rows [: int(50 * len - 0.817)] per clip.  No operator of the encoder mixes clips, so
+    clip i of the padded batch is the per-clip forward of its zero-padded waveform."""
+    longest = max(int(p.numel()) for p in pcms)
+    return [emotion2vec_features(p, model, pad_samples=longest) for p in pcms]

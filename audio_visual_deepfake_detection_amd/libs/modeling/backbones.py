@@ -74,7 +74,10 @@ class ConvHRLRFullResSelfAttTransformerBackboneRevised(nn.Module):
             x = self.embd_norm[idx](x, relu=True, pe=pe, mask=mask if pe is not None else None)
         return x
 
-    def forward(self, x, reco_x, mask):
+    def forward(self, x, reco_x, mask, cut_hook=None):
+        """`cut_hook` (engine.TrainStep): called on the stem output, the one tensor every later block depends on; the
+        engine detaches there so that the backward pass runs in phases whose gradient buckets can be all-reduced while
+        the next phase computes."""
         if self.training:
             plan_drop_path(self, x.shape[0], x.device)
         same = reco_x is None or reco_x is x
@@ -83,6 +86,8 @@ class ConvHRLRFullResSelfAttTransformerBackboneRevised(nn.Module):
         x, _ = self.resselfattention(x, mask, x_k=reco_x, mask_k=mask, x_v=x, mask_v=mask)
         for blk in self.stem:
             x, mask = blk(x, mask)
+        if cut_hook is not None:
+            x = cut_hook(x)
         lh_feat, lh_mask = x, mask
         out_feats, out_masks = [lh_feat], [lh_mask]
         n = len(self.branch)
@@ -141,12 +146,14 @@ class ConvTransformerBackbone(nn.Module):
 
     _embed = ConvHRLRFullResSelfAttTransformerBackboneRevised._embed
 
-    def forward(self, x, mask):
+    def forward(self, x, mask, cut_hook=None):
         if self.training:
             plan_drop_path(self, x.shape[0], x.device)
         x = self._embed(x, mask)
         for blk in self.stem:
             x, mask = blk(x, mask)
+        if cut_hook is not None:
+            x = cut_hook(x)
         out_feats, out_masks = [x], [mask]
         for blk in self.branch:
             x, mask = blk(x, mask)
@@ -181,10 +188,12 @@ class ConvBackbone(nn.Module):
 
     _embed = ConvHRLRFullResSelfAttTransformerBackboneRevised._embed
 
-    def forward(self, x, mask):
+    def forward(self, x, mask, cut_hook=None):
         x = self._embed(x, mask)
         for blk in self.stem:
             x, mask = blk(x, mask)
+        if cut_hook is not None:
+            x = cut_hook(x)
         out_feats, out_masks = [x], [mask]
         for blk in self.branch:
             x, mask = blk(x, mask)

@@ -288,13 +288,13 @@ class AVPtTransformerRecovery(nn.Module):
         return x, mask
 
     # ------------------------------------------------------------------------------------------
-    def forward_features(self, x, mask):
+    def forward_features(self, x, mask, cut_hook=None):
         """Network body on time-major tensors: returns (logits [B,P], offsets [B,P,2], pmask [B,P],
-        video logits [B,1], per-level lengths)."""
+        video logits [B,1], per-level lengths).  `cut_hook`: see the backbone's forward."""
         reset_mask_cache()
         self._front_input = x
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
-        feats, masks = self._run_backbone(x, reco_x, mask)
+        feats, masks = self._run_backbone(x, reco_x, mask, cut_hook)
         fpn_feats, fpn_masks = self.neck(feats, masks)
         lens = [int(f.shape[1]) for f in fpn_feats]
         gx, gmask, gidx, keep = gap_levels(fpn_feats, fpn_masks)
@@ -303,12 +303,12 @@ class AVPtTransformerRecovery(nn.Module):
         pmask = torch.cat(fpn_masks, dim=1)
         return logits, offsets, pmask, cls_scores, lens
 
-    def _run_backbone(self, x, reco_x, mask):
-        return self.backbone(x, reco_x, mask)
+    def _run_backbone(self, x, reco_x, mask, cut_hook=None):
+        return self.backbone(x, reco_x, mask, cut_hook=cut_hook)
 
     def forward(self, video_list):
         if not self.training:
-            with ops.infer_mode():             # inference: forward GEMMs in bf16x3 (5e-6 rel.), training stays exact fp32
+            with ops.infer_mode():             # exact fp32 unless bf16x3 was opted into (ops.INFER_BF16X3)
                 return self._forward(video_list)
         return self._forward(video_list)
 
@@ -459,8 +459,8 @@ class PtTransformer(AVPtTransformerRecovery):
     def _front(self, x, mask):
         return torch.zeros((x.shape[0], 1), dtype=torch.float32, device=x.device), None, None
 
-    def _run_backbone(self, x, reco_x, mask):
-        return self.backbone(x, mask)
+    def _run_backbone(self, x, reco_x, mask, cut_hook=None):
+        return self.backbone(x, mask, cut_hook=cut_hook)
 
     def _pack_gt(self, video_list, dev):
         assert all(v.get('segments') is not None for v in video_list), "GT action labels does not exist"

@@ -224,25 +224,37 @@ class Conv1dFn(torch.autograd.Function):
 
 
 BWD_PAIR = True      # K=1 layers: data + weight gradient in one launch (avdf_conv1d_bwd_pair_grouped) on the engine path
-GEMM_MODE = 0        # forward conv GEMMs: 0 = exact fp32 MFMA, 1 = split-bf16 operands (bf16x3, ~5e-6 relative error)
-INFER_BF16X3 = True  # inference paths (model.eval(), InferStep, the frozen extractors) run their forward GEMMs in bf16x3
+
+# Arithmetic mode of the forward conv GEMMs: 0 = exact fp32 MFMA (the default EVERYWHERE: training, model.eval(), the
+# extractors -- what every parity fixture is held against), 1 = split-bf16 operands ("bf16x3", ~5e-6 relative error,
+# 1.3-1.9x faster).  The mode is per THREAD on both sides of the C ABI (threading.local here, thread_local in the
+# library), so an evaluation / prefetch thread cannot change the arithmetic of a training thread.
+import threading as _threading
+
+_tls = _threading.local()
+_ENV_MODE = int(_os.environ.get("AVDF_GEMM_MODE", "0") or 0)
+# opt-in for the inference-only paths (model.eval(), InferStep, the frozen extractors); AVDF_INFER_BF16X3=1 or assignment
+INFER_BF16X3 = _os.environ.get("AVDF_INFER_BF16X3", "0") == "1"
+
+
+def current_gemm_mode():
+    return getattr(_tls, "mode", _ENV_MODE)
 
 
 def set_gemm_mode(mode):
-    """Process-wide arithmetic mode of the forward conv GEMMs (see avdf_gemm_mode)."""
-    global GEMM_MODE
-    GEMM_MODE = int(mode)
-    check(lib.avdf_gemm_mode(GEMM_MODE), "gemm_mode")
+    """Arithmetic mode of the forward conv GEMMs launched by THIS thread from now on (see avdf_gemm_mode)."""
+    check(lib.avdf_gemm_mode(int(mode)), "gemm_mode")
+    _tls.mode = int(mode)
 
 
 class gemm_mode:
-    """with ops.gemm_mode(1): ...   -- forward conv GEMMs launched inside use the given arithmetic mode."""
+    """with ops.gemm_mode(1): ...   -- forward conv GEMMs launched inside (by this thread) use the given mode."""
 
     def __init__(self, mode):
         self.mode = int(mode)
 
     def __enter__(self):
-        self.prev = GEMM_MODE
+        self.prev = current_gemm_mode()
         set_gemm_mode(self.mode)
         return self
 
@@ -251,21 +263,24 @@ class gemm_mode:
         return False
 
 
-def infer_mode():
-    """Arithmetic mode of the inference-only paths: bf16x3 unless disabled (INFER_BF16X3 / AVDF_GEMM_MODE=0)."""
-    return gemm_mode(1 if (INFER_BF16X3 and _os.environ.get("AVDF_GEMM_MODE", "") != "0") else GEMM_MODE)
+def infer_mode(bf16x3=None):
+    """Arithmetic mode of the inference-only paths: exact fp32 unless bf16x3 is asked for (argument, `INFER_BF16X3`, or
+    AVDF_INFER_BF16X3=1); an enclosing `gemm_mode(1)` is kept."""
+    want = INFER_BF16X3 if bf16x3 is None else bool(bf16x3)
+    return gemm_mode(1 if want else current_gemm_mode())
 
 
 class _ExactGemm:
-    """Force the exact-fp32 forward GEMM for the launches inside the block (launch-time host switch)."""
+    """Force the exact-fp32 forward GEMM for the launches inside the block (launch-time host switch of this thread)."""
 
     def __enter__(self):
-        if GEMM_MODE != 0:
-            lib.avdf_gemm_mode(0)
+        self.prev = current_gemm_mode()
+        if self.prev != 0:
+            set_gemm_mode(0)
 
     def __exit__(self, *a):
-        if GEMM_MODE != 0:
-            lib.avdf_gemm_mode(GEMM_MODE)
+        if self.prev != 0:
+            set_gemm_mode(self.prev)
         return False
 
 
@@ -1192,6 +1207,5 @@ def decode_nms(points, logits, offsets, pmask, pre_nms_thresh, duration_thresh, 
     return segs, scores, pidx, count
 
 
-# package default: exact fp32 everywhere in training; AVDF_GEMM_MODE=1 switches the training forward GEMMs to bf16x3 too,
-# AVDF_GEMM_MODE=0 also pins the inference paths to exact fp32
-set_gemm_mode(int(_os.environ.get("AVDF_GEMM_MODE", GEMM_MODE)))
+# package default: exact fp32 everywhere; AVDF_GEMM_MODE=1 switches every forward GEMM of the process to bf16x3
+# (the library reads the variable itself for threads that never call set_gemm_mode)

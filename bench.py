@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--bf16x3-fwd", action="store_true",
                     help="training forward GEMMs with split-bf16 operands (759 vs 712 clips/s; losses agree to 1e-6, gradient "
                          "elements to ~5e-3 instead of 1e-4 -- not the parity-checked default)")
+    ap.add_argument("--bf16x3", action="store_true",
+                    help="infer / e2e modes: split-bf16 forward GEMMs (~5e-6 relative error; exact fp32 is the default)")
     ap.add_argument("--workload", default="av", choices=["av", "audio"],
                     help="av: exp10 AV fusion, C_in = 3072 (headline; BASELINE configs 3/4); audio: BYOL-A-only features, "
                          "C_in = 2048 (BASELINE config 2) through the same exp10 architecture")
@@ -167,6 +169,7 @@ def main():
     from audio_visual_deepfake_detection_amd.engine import TrainStep, InferStep
 
     ops.BRANCH_STREAMS = args.branch_streams
+    ops.INFER_BF16X3 = bool(args.bf16x3)
     torch.manual_seed(0)                       # identical random-init weights on every rank
     global STREAMS
     if args.workload == "audio":
@@ -203,7 +206,7 @@ def main():
                         weight_decay=cfg["opt"]["weight_decay"], clip_grad_l2norm=cfg["train_cfg"]["clip_grad_l2norm"],
                         use_graph=not args.no_graph, process_group=pg, wgrad_side=args.wgrad_side, fwd_bf16x3=args.bf16x3_fwd)
     else:
-        eng = InferStep(model, B, STREAMS, use_graph=not args.no_graph)
+        eng = InferStep(model, B, STREAMS, use_graph=not args.no_graph, bf16x3=args.bf16x3)
     load_batch(eng, rank * B)
     eng.capture()
 
@@ -292,7 +295,8 @@ def main():
                                     else "BYOL-A 2048 only (BASELINE config 2 shapes: C_in = 2048 through the exp10 architecture)"),
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": 768,
                        "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
-                       "fwd_gemm": ("bf16x3" if (args.mode != "train" or args.bf16x3_fwd) else "f32"), "bwd_gemm": "f32",
+                       "fwd_gemm": ("bf16x3" if ((args.mode != "train" and args.bf16x3) or args.bf16x3_fwd) else "f32"),
+                       "bwd_gemm": "f32",
                        "dead_params_skipped": len(getattr(eng, "dead", []))},
         }
         if roof is not None:

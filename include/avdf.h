@@ -89,7 +89,8 @@ int avdf_conv1d_fwd_strided(const float* x, const float* w, const float* bias, f
 
 /* Arithmetic mode of the forward conv GEMMs: 0 = exact fp32 MFMA (default; what the parity fixtures are held
  * against), 1 = split-bf16 operands ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate,
- * ~2^-17 relative error per product).  Experimental.                                                          */
+ * ~2^-17 relative error per product).  The switch is THREAD-LOCAL host state read at launch time: it applies to the
+ * launches the calling thread issues afterwards and never to another thread's.                                 */
 int avdf_gemm_mode(int mode);
 
 /* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the
@@ -245,6 +246,13 @@ int avdf_loc_losses(const float* logits, const float* offsets, const float* pmas
 int64_t avdf_l1_mean_ws(void);
 int avdf_l1_mean(const float* a, const float* b, const float* wb, float* out, float* da, float* ws,
                  int B, int64_t per_clip, float inv_denom, void* stream);
+/* The same loss inside a captured training step (engine.TrainStep): real clips = {b : ngt[b] == 0};
+ * n_real = DEVICE float[1], the number of real clips of the GLOBAL batch (avdf_count_real, then all-reduced across
+ * data-parallel ranks); out[0] = this rank's share of the mean (nan when n_real == 0, like torch.mean of nothing),
+ * added to final_loss[0] when given; da (optional) = d out / d a.                                        */
+int avdf_count_real(const int32_t* ngt, float* out /*[1]*/, int B, void* stream);
+int avdf_l1_mean_dev(const float* a, const float* b, const int32_t* ngt, const float* n_real, float* out,
+                     float* final_loss, float* da, float* ws, int B, int64_t per_clip, void* stream);
 /* sigmoid_focal_loss(x, t, reduction='sum') (losses.py:5-53, alpha .25, gamma 2) over n elements; dx optional.
  * Used for the frame-level loss of exp13 (av_fd_no_recon2.py:718-725).                               */
 int avdf_focal_loss_sum(const float* x, const float* t, float* out, float* dx, int64_t n, void* stream);
@@ -360,7 +368,8 @@ int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, fl
  * packed once from the reference [Cout, Cin, 3, 3, 3]).                                                  */
 int avdf_conv3d_k3(const float* x, const float* wp, const float* bias, float* y, int B, int T, int H, int W,
                    int Cin, int Cout, int act, void* stream);
-/* 0 = exact fp32 MFMA (default), 1 = split-bf16 operands for the layers with Cin >= 16 (~5e-6 relative error) */
+/* 0 = exact fp32 MFMA (default), 1 = split-bf16 operands for the layers with Cin >= 16 (~5e-6 relative error).
+ * Per calling thread (thread-local host switch read at launch time), like avdf_gemm_mode.                */
 int avdf_conv3d_mode(int mode);
 /* uint8 frames [T, H0, W0, 3] -> fp32 [Tp, S, S, 4] (/255, nearest resize, 4th channel and frames >= T zero) */
 int avdf_video_prep(const uint8_t* frames, float* out, int T, int H0, int W0, int Tp, int S, void* stream);
@@ -370,11 +379,21 @@ int avdf_maxpool_hw(const float* x, float* y, int64_t N, int H, int W, int C, in
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);
 int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);
+int avdf_sumsq_ex(const float* x, float* out /*[1]*/, float* ws, int64_t n, int accumulate /*0: out is overwritten*/,
+                  void* stream);
 /* hp: DEVICE float[3] = {lr, 1-beta1^t, 1-beta2^t}, rewritten by the host each step (graph-safe schedule);
  * gnorm_sq: device float[1] = sum of squared gradients over ALL parameters (NULL or clip_norm<=0: no clipping) */
 int avdf_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
                    const float* hp, int64_t n, float beta1, float beta2, float eps, float wd,
                    float clip_norm, float ema_decay, void* stream);
+/* One launch over nseg (<= 8) consecutive ranges of the flat buffers, range i = [seg_end[i-1], seg_end[i]) with weight
+ * decay seg_wd[i] (HOST arrays; seg_end[nseg-1] == n): the decay / no-decay groups of make_optimizer
+ * (train_utils.py:125-144) of every gradient bucket in a single pass.  zero_grad != 0: g is cleared after use (the
+ * model.zero_grad() of the next iteration, train_utils.py:302, without a separate pass).                 */
+int avdf_adamw_ema_seg(float* p, const float* g, float* m, float* v, float* ema, const float* gnorm_sq,
+                       const float* hp, int64_t n, int nseg, const int64_t* seg_end, const float* seg_wd,
+                       float beta1, float beta2, float eps, float clip_norm, float ema_decay, int zero_grad,
+                       void* stream);
 
 #ifdef __cplusplus
 }

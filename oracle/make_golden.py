@@ -689,6 +689,7 @@ def main():
     case_nms_modes()
     case_datasets()
     case_metrics()
+    case_eval_detection()
     case_lr_schedules()
     case_byola_net()
     case_emotion2vec_parts()
@@ -716,10 +717,74 @@ def main():
     print("done")
 
 
+def case_eval_detection():
+    """The deepfake evaluator (libs/utils/Evaluation/eval.py:119-165, eval_detection.py:18-319): `run_evaluation` of the
+    reference on synthetic validation results -> its prediction json and its AP at tIoU {0.5, 0.75, 0.9, 0.95}.  `np.float`
+    (gone since numpy 1.24, eval_detection.py:310-311) is aliased HERE, in the generator process only; distinct scores, so
+    the hash-order of the reference's video set cannot change the result."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    if not hasattr(np, "float"):
+        np.float = float
+    from libs.utils.Evaluation import run_evaluation
+    out = {}
+    for ci, seed in enumerate((31, 32)):
+        rs = np.random.RandomState(seed)
+        gt_items, vids, ts, te, sc = [], [], [], [], []
+        for v in range(14):
+            vid = f"id{v:03d}/clip.mp4"
+            n = int(rs.randint(0, 3)) if v else 2
+            segs = [[float(s), float(s + rs.uniform(0.2, 1.5))] for s in rs.uniform(0, 8, n)]
+            gt_items.append({"video_id": vid, "n_fakes": n, "segments_time": segs})
+            if v % 6 == 5:
+                continue                                   # no predictions for this video
+            for (a, b) in segs:
+                for _ in range(int(rs.randint(1, 4))):
+                    j = rs.uniform(-0.25, 0.25, 2)
+                    vids.append(vid); ts.append(a + j[0]); te.append(max(a + j[0] + 0.05, b + j[1])); sc.append(float(rs.uniform(0, 1)))
+            for _ in range(int(rs.randint(0, 3))):
+                s0 = float(rs.uniform(-0.3, 9))
+                vids.append(vid); ts.append(s0); te.append(s0 + float(rs.uniform(0.1, 1))); sc.append(float(rs.uniform(0, 1)))
+        assert len(set(sc)) == len(sc)
+        preds = {"video-id": vids, "t-start": np.asarray(ts, np.float32), "t-end": np.asarray(te, np.float32),
+                 "label": np.zeros(len(vids), np.int64), "score": np.asarray(sc, np.float32)}
+        cls_file = None
+        if ci == 1:                                        # with the external video-level scores
+            f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+            json.dump({g["video_id"]: [float(rs.uniform(0.2, 1)), float(rs.uniform(0.2, 1))] for g in gt_items}, f)
+            f.close()
+            cls_file = f.name
+        pf = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False).name
+        # the reference fans the per-video formatting out to 16 loky PROCESSES (eval.py:137, a soft `prefer=`); fresh
+        # worker processes cannot re-import `libs` here (the torchsort stub lives in this process only), so the same
+        # joblib call is served by threads -- same function, same results
+        import joblib
+        with contextlib.redirect_stdout(io.StringIO()), joblib.parallel_backend("threading"):
+            mAP, _ = run_evaluation(preds, gt_items, pf, cls_score_file=cls_file)
+        from libs.utils.Evaluation.eval_detection import ANETdetection
+        with contextlib.redirect_stdout(io.StringIO()):
+            det = ANETdetection(ground_truth_filename=gt_items, prediction_filename=pf, subset="test")
+            m, avg = det.evaluate()
+        pj = json.load(open(pf))
+        out[f"c{ci}_seed"] = np.array(seed)
+        out[f"c{ci}_gt"] = np.array(json.dumps(gt_items))
+        out[f"c{ci}_cls"] = np.array(json.dumps(json.load(open(cls_file))) if cls_file else "")
+        out[f"c{ci}_vid"] = np.array(vids)
+        out[f"c{ci}_tab"] = np.stack([preds["t-start"], preds["t-end"], preds["score"]], 1)
+        out[f"c{ci}_mAP"], out[f"c{ci}_avg"], out[f"c{ci}_ret"] = m, np.array(avg), np.array(mAP)
+        out[f"c{ci}_pred_json"] = np.array(json.dumps(pj, sort_keys=True))
+        out[f"c{ci}_report"] = np.array(open(pf.replace(".json", ".txt")).read())
+        print(f"[eval_detection] case {ci}: mAP {m}, mean x100 {mAP:.3f}")
+    np.savez_compressed(os.path.join(GOLD, "eval_detection.npz"), **out)
+
+
 NAMED = {
     "metrics": lambda ctx: case_metrics(),
     "nms_modes": lambda ctx: case_nms_modes(),
     "lr": lambda ctx: case_lr_schedules(),
+    "eval_detection": lambda ctx: case_eval_detection(),
     "byola_net": lambda ctx: case_byola_net(),
     "emotion2vec_parts": lambda ctx: case_emotion2vec_parts(),
     "optimizer_split": case_optimizer_split,

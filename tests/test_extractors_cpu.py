@@ -83,3 +83,38 @@ def attn_fixture_inputs(g):
     scale = torch.from_numpy((0.5 + rs.uniform(0, 1, heads)).astype(np.float32))
     assert np.array_equal(scale.numpy(), g["attn_scale"])
     return sd, x, scale
+
+
+def test_mel_filterbank_known_answers_of_the_htk_formula():
+    """The log-mel front-end's filterbank (torchaudio melscale_fbanks, mel_scale='htk', norm=None -- torchaudio itself is
+    absent) against answers worked out by hand from the published formula mel(f) = 2595 log10(1 + f/700): band edges,
+    the first non-zero bin, the partition-of-unity property of un-normalised triangles, and peak positions.  Holds for
+    the oracle's filterbank AND the product's (the constant the HIP GEMM consumes)."""
+    import math
+    import numpy as np
+    from oracle import byola_ref as BR
+    from audio_visual_deepfake_detection_amd.extractors.byola import melscale_fbanks_htk
+    mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    inv = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    m_lo, m_hi = mel(60.0), mel(7800.0)
+    # by hand: log10(1 + 60/700) = log10(1.085714) = 0.0357155 -> 92.682; log10(1 + 7800/700) = log10(12.142857) = 1.0843209 -> 2813.81
+    assert abs(m_lo - 92.682) < 1e-3 and abs(m_hi - 2813.81) < 1e-2
+    edges = [inv(m_lo + (m_hi - m_lo) * i / 65.0) for i in range(66)]                # 64 triangles share 66 edges
+    assert abs(edges[0] - 60.0) < 1e-9 and abs(edges[65] - 7800.0) < 1e-8
+    # second edge by hand: mel = 92.682 + (2813.813 - 92.682) / 65 = 134.546 -> 700 * (10^(134.546 / 2595) - 1) = 700 * 0.126803 = 88.76 Hz
+    assert abs(edges[1] - 88.76) < 0.01
+    freqs = [k * 8000.0 / 512.0 for k in range(513)]                                 # n_fft 1024 at 16 kHz: 15.625 Hz bins
+    for name, fb in (("oracle", BR.mel_fbanks().numpy()), ("product", melscale_fbanks_htk(513, 60.0, 7800.0, 64, 16000))):
+        assert fb.shape == (513, 64) and fb.dtype == np.float32
+        assert float(np.abs(fb[:4]).max()) == 0.0, name                              # bins 0..46.9 Hz lie below f_min = 60 Hz
+        want = (62.5 - 60.0) / (edges[1] - 60.0)                                     # bin 4 = 62.5 Hz on the first up-slope
+        assert abs(float(fb[4, 0]) - want) < 1e-6 and float(np.abs(fb[4, 1:]).max()) == 0.0, name
+        assert float(fb.max()) <= 1.0 + 1e-6 and float(fb.min()) >= 0.0
+        inside = [k for k, f in enumerate(freqs) if edges[1] <= f <= edges[64]]
+        assert np.allclose(fb[inside].sum(axis=1), 1.0, atol=2e-6), name             # down-slope(i) + up-slope(i+1) = 1
+        assert float(np.abs(fb[[k for k, f in enumerate(freqs) if f >= 7800.0]]).max()) == 0.0, name
+        for j in (0, 17, 40, 63):                                                    # triangle j: edges j, j+1 (peak), j+2
+            k_peak = int(np.argmax(fb[:, j]))
+            assert abs(freqs[k_peak] - edges[j + 1]) <= 15.625 / 2 + 1e-9, (name, j)
+            k = next(i for i, f in enumerate(freqs) if edges[j] < f < edges[j + 1])
+            assert abs(float(fb[k, j]) - (freqs[k] - edges[j]) / (edges[j + 1] - edges[j])) < 1e-6, (name, j)

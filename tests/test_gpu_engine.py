@@ -139,3 +139,134 @@ def test_audio_only_workload_steps():
     assert all(np.isfinite(v) for v in ls.values()), ls
     assert ls["num_pos"] > 0
     assert float((eng.flat_p - before).abs().max()) > 0
+
+
+def test_ten_step_trajectory_matches_oracle_with_torch_adamw():
+    """Ten engine steps queued back to back (no host synchronisation between them: the lr / bias-correction scalars of every
+    step travel through their own pinned slot) under a warm-up + cosine schedule, against the CPU oracle driven by
+    clip_grad_norm_ + torch.optim.AdamW (the reference's step, train_utils.py:302-316): loss trajectory, loss normaliser and
+    final weights.  deterministic=True: slab reducers instead of float atomics -> two runs are bit-identical."""
+    from audio_visual_deepfake_detection_amd import build_model
+    from audio_visual_deepfake_detection_amd.engine import TrainStep, split_decay
+    from audio_visual_deepfake_detection_amd.libs.utils.lr_schedulers import LinearWarmupCosineAnnealingLR
+    from oracle import ummaformer_ref as R
+    cfg = R.make_cfg(input_dim=96, max_seq_len=192, embd_dim=32, n_head=4, fpn_dim=32, head_dim=32)
+    sd0 = R.synth_state_dict(R.param_shapes(cfg), 29, True)
+    sched = LinearWarmupCosineAnnealingLR(2e-3, 3, 12)
+    nstep, B = 10, 4
+
+    def run_engine():
+        model, _ = build_model("deepfake_exp10.yaml", **SMALL)
+        model.load_state_dict(sd0)
+        model = model.to("cuda:0")
+        for mod in model.modules():
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0
+        model.interpolator.dp1.p = 0.0
+        eng = TrainStep(model, B, STREAMS, lr=0.0, weight_decay=0.05, clip_grad_l2norm=1.0, use_graph=True, deterministic=True)
+        eng.set_lr_schedule(sched)
+        clips = _fill(eng, 41)
+        eng.capture()
+        traj = []
+        for _ in range(nstep):
+            eng.step()
+            traj.append(eng.loss_out.clone())              # device-side copy: no host sync inside the loop
+        torch.cuda.synchronize()
+        return eng, model, clips, torch.stack(traj).cpu()
+
+    eng, model, clips, traj = run_engine()
+    eng2, _, _, traj2 = run_engine()
+    assert torch.equal(traj, traj2) and torch.equal(eng.flat_p, eng2.flat_p), "deterministic engine runs differ"
+
+    # --- oracle + torch.optim.AdamW on the CPU ---------------------------------------------------------------
+    torch.set_num_threads(8)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    decay, no_decay = split_decay(model)
+    dead = set(eng.dead)
+    opt = torch.optim.AdamW([{"params": [sd[n] for n in decay if n not in dead], "weight_decay": 0.05},
+                             {"params": [sd[n] for n in no_decay if n not in dead], "weight_decay": 0.0}], lr=1e-3)
+    x = torch.stack([R.interp_concat(c["streams"], 192) for c in clips])
+    mask = torch.ones((B, 1, 192))
+    gts = [c["segments"] for c in clips]
+    gls = [c["labels"] for c in clips]
+    norm = cfg["init_loss_norm"]
+    live = [sd[n] for n in sd if n not in dead]
+    for it in range(nstep):
+        for g in opt.param_groups:
+            g["lr"] = sched(it)
+        opt.zero_grad(set_to_none=True)
+        out = R.model_forward(sd, cfg, x, mask, training=True)
+        ls, norm, npos = R.losses(cfg, out, gts, gls, norm)
+        ls["final_loss"].backward()
+        torch.nn.utils.clip_grad_norm_(live, 1.0)
+        opt.step()
+        got = traj[it]
+        # two fp32 implementations drift apart along an Adam trajectory (every element's step is normalised to ~lr, so
+        # rounding noise in small gradients is amplified step by step): tight over the first steps, looser afterwards
+        tol = 2e-4 if it < 5 else 3e-3
+        for j, k in enumerate(("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")):
+            assert abs(float(got[j]) - float(ls[k])) < tol * max(1.0, abs(float(ls[k]))), (it, k, float(got[j]), float(ls[k]))
+        assert float(got[4]) == float(npos)
+    assert abs(model.loss_normalizer - norm) < 1e-3
+    new = dict(model.named_parameters())
+    worst = 0.0
+    for n in sd:
+        if n in dead:
+            continue
+        delta_ref = sd[n].detach() - sd0[n]
+        delta_got = new[n].detach().cpu() - sd0[n]
+        # Adam's per-element normalisation turns the rounding noise of (mathematically) zero gradients into +-lr steps in
+        # either implementation: compare where the reference moved by more than that noise floor
+        sel = delta_ref.abs() > 0.25 * float(delta_ref.abs().max())
+        if sel.any() and float(delta_ref.abs().max()) > 1e-4:
+            worst = max(worst, float(((delta_got - delta_ref)[sel].abs() / delta_ref[sel].abs()).max()))
+    assert worst < 5e-2, worst
+
+
+def test_engine_step_of_exp5_includes_the_reconstruction_loss():
+    """exp5 (`AVLocPointTransformerRecoveryNoNorm`): the L1 reconstruction term on the real clips (av_fd_meta_arch.py:683-701)
+    is part of final_loss and sends gradient into interpolator.expansion.* -- the engine step must equal the plain
+    `model(video_list)` path, and the Expansion parameters must be live."""
+    from audio_visual_deepfake_detection_amd import build_model
+    from audio_visual_deepfake_detection_amd.engine import TrainStep
+    torch.manual_seed(4)
+    model, _ = build_model("deepfake_exp5.yaml", **SMALL)
+    model = model.to("cuda:0")
+    for mod in model.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    model.interpolator.dp1.p = 0.0
+    ref = copy.deepcopy(model).train()
+    eng = TrainStep(model, 4, STREAMS, lr=1e-3, use_graph=True)
+    assert eng.has_reco and not any(n.startswith("interpolator.expansion") for n in eng.dead)
+    assert [b[0] for b in eng.bucket_ranges] == ["post", "pre"]
+    clips = _fill(eng, 8)
+    eng.capture()
+    eng.step()
+    got = eng.losses()
+    losses = ref(clips)
+    for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss", "reco_loss"):
+        assert abs(got[k] - float(losses[k])) < 2e-5 * max(1.0, abs(float(losses[k]))), (k, got[k], float(losses[k]))
+    losses["final_loss"].backward()
+    # Adam's first moment after one step = 0.1 * clipped gradient: linear in the gradient, comparable element-wise
+    named = dict(ref.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)).item()
+    cs = min(1.0, 1.0 / (gn + 1e-6))
+    for n in ("interpolator.expansion.up_1.conv_transpose.conv.weight", "interpolator.expansion.up_5.conv_transpose.conv.bias",
+              "backbone.resselfattention.attn.key.weight", "interpolator.contraction.down_2.conv_block.conv.weight"):
+        off, k = eng._offsets[n], named[n].numel()
+        m1 = eng.exp_avg[off:off + k].view(named[n].shape)
+        want = 0.1 * cs * named[n].grad
+        assert float((m1 - want).abs().max()) < 1e-3 * float(want.abs().max()) + 1e-9, n
+
+
+def test_probe_leaves_inputs_and_rng_untouched():
+    from audio_visual_deepfake_detection_amd.engine import TrainStep
+    model, _ = _model(6)
+    torch.manual_seed(77)
+    a = torch.rand(3, device="cuda:0")
+    torch.manual_seed(77)
+    eng = TrainStep(model, 2, STREAMS, use_graph=False)
+    b = torch.rand(3, device="cuda:0")
+    assert torch.equal(a, b), "constructing the engine consumed device RNG"
+    assert float(eng.gt.abs().sum()) == 0.0 and int(eng.ngt.sum()) == 0 and float(eng.x.abs().sum()) == 0.0

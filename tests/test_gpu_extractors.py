@@ -266,3 +266,87 @@ def test_softmax_alibi_heads_all_paths(H, T, ld):
     out = sd.cpu().double()
     assert float((out[:, :, :T] - ref).abs().max()) < 2e-6
     assert float(out[:, :, T:].abs().max()) == 0.0 if ld > T else True
+
+
+def test_byola_batch_pad_mode_equals_reference_collate_semantics():
+    """extract_audio_feature_batch.py:65-81,111-123: normalised log-mels zero-padded to the batch maximum, network on the padded
+    images, features saved untrimmed.  Checked against the (reference-pinned) network oracle run on the SAME padded batch; the
+    shorter clip must differ from its un-padded features near its end (that is the point of the mode)."""
+    from audio_visual_deepfake_detection_amd.extractors import LogMelFrontEnd, byola_features, byola_features_batch
+    from oracle import byola_ref as R
+    m = _model(5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    pcms = [torch.rand(n, generator=g) - 0.5 for n in (48000, 30000 + 77, 16000)]
+    md, fe = m.to("cuda:0"), LogMelFrontEnd().to("cuda:0")
+    got = byola_features_batch([p.to("cuda:0") for p in pcms], md, fe)
+    lms = [R.log_mel(p) for p in pcms]
+    tmax = max(l.shape[1] for l in lms)
+    batch = torch.zeros(len(pcms), 1, 64, tmax)
+    for i, l in enumerate(lms):
+        batch[i, 0, :, :l.shape[1]] = l
+    ref = R.byola_forward(sd, batch)
+    for i in range(len(pcms)):
+        assert got[i].shape == ref[i].shape == (tmax // 8, 2048)
+        assert float((got[i].cpu() - ref[i]).abs().max() / ref[i].abs().max()) < 1e-3
+    alone = byola_features(pcms[2].to("cuda:0"), md, fe)
+    n = alone.shape[0]
+    assert float((got[2][:n - 2] - alone[:n - 2]).abs().max()) < 1e-3 * float(alone.abs().max())     # interior rows agree
+    assert float((got[2][n - 1] - alone[n - 1]).abs().max()) > 1e-3 * float(alone.abs().max())       # the boundary row does not
+
+
+def test_emotion2vec_batch_pad_mode_equals_reference_collate_semantics():
+    """scripts/extract_audio_feature_batch.py:35-52,73-91: zero-padded PCM, padding_mask=None (attention sees the padding),
+    rows [: int(50 * len - 0.817)] per clip -- against the restatement run on the same zero-padded batch."""
+    from audio_visual_deepfake_detection_amd.extractors import Emotion2Vec, emotion2vec_features, emotion2vec_features_batch
+    from oracle import emotion2vec_ref as R
+    torch.manual_seed(13)
+    m = Emotion2Vec(depth=1, prenet_depth=1)
+    with torch.no_grad():
+        m.modality_encoders["AUDIO"].alibi_scale.uniform_(0.5, 1.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(31)
+    pcms = [torch.rand(n, generator=g) - 0.5 for n in (24000, 16000 + 50)]
+    md = m.to("cuda:0")
+    got = emotion2vec_features_batch([p.to("cuda:0") for p in pcms], md)
+    batch = torch.zeros(2, 24000)
+    for i, p in enumerate(pcms):
+        batch[i, :p.numel()] = p
+    ref = R.forward(sd, batch, heads=12, prenet_depth=1, depth=1)
+    for i, p in enumerate(pcms):
+        k = int(50 * (p.numel() / 16000.0) - 0.817)
+        assert got[i].shape == (k, 768)
+        assert float((got[i].cpu() - ref[i, :k]).abs().max() / ref[i].abs().max()) < 1e-3
+    alone = emotion2vec_features(pcms[1].to("cuda:0"), md)
+    assert float((got[1] - alone).abs().max()) > 1e-3 * float(alone.abs().max())      # the padded clip is "contaminated"
+
+
+def test_emotion2vec_attention_matches_reference_alt_attention(golden_dir):
+    """The HIP attention of one layer (q/k/v GEMMs, QK^T + ALiBi + softmax, PV, proj) against the output of the REFERENCE's own
+    AltAttention + get_alibi_bias (tests/golden/emotion2vec_parts.npz, written by oracle/make_golden.py emotion2vec_parts)."""
+    import os
+    from audio_visual_deepfake_detection_amd.extractors import Emotion2Vec
+    from tests.test_extractors_cpu import attn_fixture_inputs
+    g = np.load(os.path.join(golden_dir, "emotion2vec_parts.npz"))
+    sd, x, scale = attn_fixture_inputs(g)
+    B, N, dim, heads = [int(v) for v in g["attn_shape"]]
+    m = Emotion2Vec(depth=1, prenet_depth=1)
+    blk = m.blocks[0]
+    blk.attn.load_state_dict({k[len("attn."):]: v for k, v in sd.items()})
+    with torch.no_grad():
+        a = m.modality_encoders["AUDIO"].alibi_scale                   # [2 layers, 1, 12, 1, 1]; layer index 1 = blocks[0]
+        a[1, 0, :, 0, 0] = scale
+    md = m.to("cuda:0")
+    Np = (N + 3) // 4 * 4
+    for use_alibi, key in ((True, "attn_out_alibi"), (False, "attn_out_plain")):
+        if not use_alibi:
+            with torch.no_grad():
+                md.modality_encoders["AUDIO"].alibi_scale.zero_()          # slope * 0: no positional bias
+        for b in range(B):
+            xp = torch.zeros((Np, dim), device="cuda:0")
+            xp[:N] = x[b].to("cuda:0")
+            with torch.no_grad():
+                out = md._attention(xp, md.blocks[0].attn, N, 1)[:N].cpu()
+            ref = torch.from_numpy(g[key][b])
+            err = float((out - ref).abs().max() / ref.abs().max())
+            assert err < 1e-4, (key, b, err)

@@ -494,10 +494,10 @@ def test_conv1d_forward_bf16x3_mode(ops, case):
     B, T, Cin, Cout, K, s = case
     x, w, b = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, K, seed=2, scale=(Cin * K) ** -0.5), rnd(Cout, seed=3)
     ref = F.conv1d(x.transpose(1, 2), w, b, s, K // 2).transpose(1, 2)
-    assert ops.GEMM_MODE == 0
+    assert ops.current_gemm_mode() == 0
     with ops.gemm_mode(1):
         y1 = ops.conv1d(g32(x), g32(w), g32(b), None, s)
-    assert ops.GEMM_MODE == 0
+    assert ops.current_gemm_mode() == 0
     y0 = ops.conv1d(g32(x), g32(w), g32(b), None, s)
     close(y1, ref, "bf16x3 conv fwd", rtol=2e-5)
     close(y0, ref, "fp32 conv fwd", rtol=2e-6 if Cin * K < 4096 else 5e-6)
