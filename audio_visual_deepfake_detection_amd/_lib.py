@@ -102,6 +102,11 @@ SIGNATURES = {
     "avdf_video_prep": (I, [P, P, I, I, I, I, I, P]),
     "avdf_maxpool_hw": (I, [P, P, L, I, I, I, I, P]),
     "avdf_softmax_alibi": (I, [P, I, I, F, F, P]),
+    "avdf_gap_concat_fwd": (I, [P, P, P, I, P, P, I, I, P]),
+    "avdf_gap_concat_bwd": (I, [P, P, P, I, I, I, P]),
+    "avdf_head_out_fwd": (I, [P, P, P, I, P, I, I, I, P]),
+    "avdf_head_out_bwd": (I, [P, P, P, P, P, P, I, P, I, I, I, P]),
+    "avdf_mask_pyramid": (I, [P, P, I, I, I, I, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
     "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),

@@ -333,24 +333,26 @@ class TrainStep:
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, self.dev)
         pool = torch.cuda.graph_pool_handle()
-        ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, pool=pool, stream=s):
-            self._stage_a()
-        gbs = []
-        for i in range(len(self._phases)):
+
+        def grab(fns):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, stream=s):
-                if i == 0:
-                    self._stage_loss()
-                self._stage_bwd(i)
-            gbs.append(g)
-        gc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gc, pool=pool, stream=s):
-            self._stage_c()
+                for fn in fns:
+                    fn()
+            return g
+
+        nph = len(self._phases)
+        bwd = [(lambda i=i: self._stage_bwd(i)) for i in range(nph)]
+        if self.world == 1:
+            # no exchange between the stages: the whole step is ONE graph launch
+            self.graphs = ([grab([self._stage_a, self._stage_loss] + bwd + [self._stage_c])], None, None)
+        else:
+            ga = grab([self._stage_a])
+            gbs = [grab(([self._stage_loss] if i == 0 else []) + [bwd[i]]) for i in range(nph)]
+            self.graphs = (ga, gbs, grab([self._stage_c]))
         with torch.cuda.stream(s):
             self.flat_g.zero_()                  # capture does not execute, but keep the invariant explicit
         torch.cuda.current_stream().wait_stream(s)
-        self.graphs = (ga, gbs, gc)
 
     def set_lr(self, lr):
         self.lr = lr
@@ -394,40 +396,42 @@ class TrainStep:
         with torch.cuda.stream(self.stream):
             self._push_hparams()
             graphs = self.graphs
-            if graphs is not None:
-                graphs[0].replay()
+            if graphs is not None and graphs[1] is None:
+                graphs[0][0].replay()                      # world size 1: one graph holds the whole step
             else:
-                self._stage_a()
-            if dist:
-                dp.allreduce_sum_(self.counts, group=self.pg)
-            works = []
-            nph = len(self._phases)
-            assert nph == len(self.bucket_ranges)
-            for i in range(nph):
                 if graphs is not None:
-                    graphs[1][i].replay()
+                    graphs[0].replay()
                 else:
-                    if i == 0:
-                        self._stage_loss()
-                    self._stage_bwd(i)
+                    self._stage_a()
                 if dist:
-                    works.append(self._reduce_bucket(i))
-            ev0 = ev1 = None
-            if dist and self.comm_events is not None:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            for w in works:
-                if w is not None and self.overlap:
-                    w.wait()
-            if ev0 is not None:
-                ev1.record()
-                self.comm_events = (ev0, ev1)
-            if graphs is None:
-                self._outs = None
-            if graphs is not None:
-                graphs[2].replay()
-            else:
-                self._stage_c()
+                    dp.allreduce_sum_(self.counts, group=self.pg)
+                works = []
+                nph = len(self._phases)
+                assert nph == len(self.bucket_ranges)
+                for i in range(nph):
+                    if graphs is not None:
+                        graphs[1][i].replay()
+                    else:
+                        if i == 0:
+                            self._stage_loss()
+                        self._stage_bwd(i)
+                    if dist:
+                        works.append(self._reduce_bucket(i))
+                ev0 = ev1 = None
+                if dist and self.comm_events is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                for w in works:
+                    if w is not None and self.overlap:
+                        w.wait()
+                if ev0 is not None:
+                    ev1.record()
+                    self.comm_events = (ev0, ev1)
+                if graphs is not None:
+                    graphs[2].replay()
+                else:
+                    self._outs = None
+                    self._stage_c()
         cur.wait_stream(self.stream)
 
     def losses(self, reduce=True):

@@ -94,8 +94,11 @@ class C3DVideoEncoder(nn.Module):
         for (wp, b), (_, pool) in zip(self._packed[0], self._plan):
             cout, cin = wp.shape[3], wp.shape[4]
             y = torch.empty((B, T, H, W, cout), dtype=torch.float32, device=x.device)
-            check(lib.avdf_conv3d_k3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), B, T, H, W, cin, cout,
-                                     ops.ACT_LEAKY, st), "conv3d_k3")
+            # cin of the packed weights is padded to 4 for the first layer: algorithmic FLOPs use the real 3 input channels
+            fl = 2.0 * B * T * H * W * cout * (3 if cin == 4 else cin) * 27
+            ops._timed("conv3d_k3", fl, lambda: check(
+                lib.avdf_conv3d_k3(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), B, T, H, W, cin, cout,
+                                   ops.ACT_LEAKY, st), "conv3d_k3"))
             x = y
             if pool:
                 y = torch.empty((B, T, H // pool, W // pool, cout), dtype=torch.float32, device=x.device)

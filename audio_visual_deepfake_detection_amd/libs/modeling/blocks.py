@@ -30,12 +30,27 @@ def reset_mask_cache():
     _MASK_CACHE.clear()
 
 
+def _mask_key(mask, stride):
+    return (mask.data_ptr(), tuple(mask.shape), tuple(mask.stride()), stride, mask._version)
+
+
+def prime_mask_pyramid(mask, n_levels, stride=2):
+    """All pyramid masks of a forward in ONE launch (ops.mask_pyramid) instead of one strided copy per level; later
+    `downsample_mask` calls of the interpolator, the backbone branches and the FPN hit the cache."""
+    if not mask.is_cuda or mask.shape[1] % (stride ** n_levels) != 0:
+        return
+    cur = mask
+    for nxt in ops.mask_pyramid(mask, n_levels, stride):
+        _MASK_CACHE[_mask_key(cur, stride)] = (cur, nxt)
+        cur = nxt
+
+
 def downsample_mask(mask, stride):
     """Nearest-neighbour mask downsampling of MaskedConv1D (blocks.py:51-55) == mask[:, ::stride].  Every strided block
     asks for the same pyramid masks (attention, pooling skip, MLP): one strided copy per (mask, stride) per forward."""
     if stride == 1:
         return mask
-    key = (mask.data_ptr(), tuple(mask.shape), tuple(mask.stride()), stride, mask._version)
+    key = _mask_key(mask, stride)
     hit = _MASK_CACHE.get(key)
     if hit is None:
         hit = (mask, mask[:, ::stride].contiguous())          # keeps `mask` alive: its address cannot be recycled

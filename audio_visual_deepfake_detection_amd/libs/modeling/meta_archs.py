@@ -12,7 +12,8 @@ import torch
 from torch import nn
 
 from .models import register_meta_arch, make_backbone, make_neck, make_generator
-from .blocks import MaskedConv1D, Scale, LayerNorm, DeepInterpolator, SegmentandCls, reset_mask_cache
+from .blocks import (MaskedConv1D, Scale, LayerNorm, DeepInterpolator, SegmentandCls, reset_mask_cache,
+                     prime_mask_pyramid)
 from ... import ops
 
 
@@ -23,38 +24,32 @@ def gap_levels(fpn_feats, fpn_masks):
     """The FPN levels of a batch as ONE sequence [B, sum(T_l + 1), C]: an all-zero row after every level plays
     the zero padding of that level's k3 convs, so the heads (weights shared across levels, av_fd_no_recon.py:75-89,
     144-159) run as one launch per layer instead of one per level.  Returns (x, mask with zeros at the gap rows,
-    int64 index of the real rows in level order, 0/1 row vector that is 0 only at the gap rows: LayerNorm+ReLU turn
-    a zero row into relu(beta), so the gaps are re-zeroed after every norm -- masked real rows are NOT, as in the
-    reference)."""
+    per-level lengths, 0/1 row vector that is 0 only at the gap rows: LayerNorm+ReLU turn a zero row into relu(beta),
+    so the gaps are re-zeroed after every norm -- masked real rows are NOT, as in the reference).  One HIP launch
+    (ops.gap_concat); the head outputs are brought back to point order by ops.head_out."""
     B, _, C = fpn_feats[0].shape
     dev = fpn_feats[0].device
     lens = tuple(int(f.shape[1]) for f in fpn_feats)
-    key = (B, C, lens, dev)
-    hit = _GAP_CACHE.get(key)
-    if hit is None:
-        idx, off = [], 0
+    key = (B, lens, dev)
+    keep = _GAP_CACHE.get(key)
+    if keep is None:
+        off, rows = 0, []
         for n in lens:
-            idx.append(torch.arange(off, off + n))
+            rows.append(torch.arange(off, off + n))
             off += n + 1
-        idx = torch.cat(idx)
         keep = torch.zeros((B, off), dtype=torch.float32)
-        keep[:, idx] = 1.0
-        hit = (torch.zeros((B, 1, C), dtype=torch.float32, device=dev), torch.zeros((B, 1), dtype=torch.float32, device=dev),
-               idx.to(dev), keep.to(dev))
-        _GAP_CACHE[key] = hit
-    z, zm, idx, keep = hit
-    xs, ms = [], []
-    for f, m in zip(fpn_feats, fpn_masks):
-        xs += [f, z]
-        ms += [m, zm]
-    return torch.cat(xs, dim=1), torch.cat(ms, dim=1), idx, keep
+        keep[:, torch.cat(rows)] = 1.0
+        keep = keep.to(dev)
+        _GAP_CACHE[key] = keep
+    x, gmask = ops.gap_concat(list(fpn_feats), list(fpn_masks))
+    return x, gmask, lens, keep
 
 
 def split_levels(y, lens):
     out, off = tuple(), 0
     for n in lens:
         out += (y[:, off:off + n],)
-        off += n + 1
+        off += n
     return out
 
 
@@ -87,8 +82,8 @@ class PtTransformerClsHead(nn.Module):
 
     def forward(self, fpn_feats, fpn_masks):
         assert len(fpn_feats) == len(fpn_masks)
-        x, gmask, _, keep = gap_levels(fpn_feats, fpn_masks)
-        return split_levels(self.forward_gapped(x, gmask, keep), [f.shape[1] for f in fpn_feats])
+        x, gmask, lens, keep = gap_levels(fpn_feats, fpn_masks)
+        return split_levels(ops.head_out(self.forward_gapped(x, gmask, keep), lens), lens)
 
 
 class PtTransformerRegHead(nn.Module):
@@ -114,14 +109,12 @@ class PtTransformerRegHead(nn.Module):
             cur, _ = self.head[idx](cur, gmask)
             cur = ops.scale_rows(self.norm[idx](cur, relu=True), keep)
         y = ops.smallconv(cur, self.offset_head.conv.weight, self.offset_head.conv.bias, gmask)
-        # per-level Scale then ReLU (av_fd_no_recon.py:155-156) as one row-scale vector over the gapped sequence
-        rs = torch.cat([self.scale[l].scale.reshape(1).expand(n + 1) for l, n in enumerate(lens)])
-        return torch.relu(y * rs[None, :, None])
+        # per-level Scale then ReLU (av_fd_no_recon.py:155-156) fused into the compaction to point order [B, P, 2]
+        return ops.head_out(y, lens, relu=True, scales=[self.scale[l].scale for l in range(len(lens))])
 
     def forward(self, fpn_feats, fpn_masks):
         assert len(fpn_feats) == len(fpn_masks) == self.fpn_levels
-        lens = [f.shape[1] for f in fpn_feats]
-        x, gmask, _, keep = gap_levels(fpn_feats, fpn_masks)
+        x, gmask, lens, keep = gap_levels(fpn_feats, fpn_masks)
         return split_levels(self.forward_gapped(x, gmask, keep, lens), lens)
 
 
@@ -292,15 +285,16 @@ class AVPtTransformerRecovery(nn.Module):
         """Network body on time-major tensors: returns (logits [B,P], offsets [B,P,2], pmask [B,P],
         video logits [B,1], per-level lengths).  `cut_hook`: see the backbone's forward."""
         reset_mask_cache()
+        prime_mask_pyramid(mask, len(self.fpn_strides) - 1, self.scale_factor)
         self._front_input = x
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
         feats, masks = self._run_backbone(x, reco_x, mask, cut_hook)
         fpn_feats, fpn_masks = self.neck(feats, masks)
-        lens = [int(f.shape[1]) for f in fpn_feats]
-        gx, gmask, gidx, keep = gap_levels(fpn_feats, fpn_masks)
-        logits = self.cls_head.forward_gapped(gx, gmask, keep).index_select(1, gidx).squeeze(-1)
-        offsets = self.reg_head.forward_gapped(gx, gmask, keep, lens).index_select(1, gidx)
-        pmask = torch.cat(fpn_masks, dim=1)
+        gx, gmask, lens, keep = gap_levels(fpn_feats, fpn_masks)
+        lens = list(lens)
+        logits = ops.head_out(self.cls_head.forward_gapped(gx, gmask, keep), lens).squeeze(-1)
+        offsets = self.reg_head.forward_gapped(gx, gmask, keep, lens)
+        pmask = ops.head_out(gmask.unsqueeze(-1), lens).squeeze(-1)             # point-order mask = gapped mask compacted
         return logits, offsets, pmask, cls_scores, lens
 
     def _run_backbone(self, x, reco_x, mask, cut_hook=None):

@@ -1001,6 +1001,100 @@ def transpose_last2(x):
 
 
 # --------------------------------------------------------------------------------------------
+# pyramid glue: gapped level sequence for the shared heads, compaction of their outputs, mask pyramid
+# --------------------------------------------------------------------------------------------
+def _int_table(v):
+    return (ctypes.c_int * len(v))(*[int(i) for i in v])
+
+
+class GapConcatFn(torch.autograd.Function):
+    """levels [B, T_l, C] x L (+ their masks [B, T_l] x L) -> ([B, sum(T_l + 1), C], gapped mask [B, sum(T_l + 1)]) with an
+    all-zero row after every level (see meta_archs.gap_levels).  One launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, n_levels, *args):
+        xs = [_c(t) for t in args[:n_levels]]
+        ms = [_c(t) for t in args[n_levels:]]
+        assert len(ms) == n_levels
+        B, _, C = xs[0].shape
+        lens = [int(t.shape[1]) for t in xs]
+        for t in xs + ms:
+            _p(t)
+        Tg = sum(lens) + n_levels
+        out = torch.empty((B, Tg, C), dtype=torch.float32, device=xs[0].device)
+        gmask = torch.empty((B, Tg), dtype=torch.float32, device=xs[0].device)
+        check(lib.avdf_gap_concat_fwd(_ptr_table(xs), _ptr_table(ms), _int_table(lens), n_levels, _p(out), _p(gmask), B, C,
+                                      _stream()), "gap_concat_fwd")
+        ctx.cfg = (B, C, lens)
+        ctx.mark_non_differentiable(gmask)
+        return out, gmask
+
+    @staticmethod
+    def backward(ctx, dout, _dmask):
+        B, C, lens = ctx.cfg
+        dout = dout.contiguous()
+        need = ctx.needs_input_grad[1:1 + len(lens)]
+        dxs = [torch.empty((B, n, C), dtype=torch.float32, device=dout.device) if nd else None for n, nd in zip(lens, need)]
+        check(lib.avdf_gap_concat_bwd(_p(dout), _ptr_table(dxs), _int_table(lens), len(lens), B, C, _stream()), "gap_concat_bwd")
+        return (None, *dxs, *([None] * len(lens)))
+
+
+def gap_concat(levels, masks):
+    return GapConcatFn.apply(len(levels), *levels, *masks)
+
+
+class HeadOutFn(torch.autograd.Function):
+    """y [B, Tg, NC] on the gapped sequence -> [B, P, NC] in point order, optionally relu(y * scale_level)."""
+
+    @staticmethod
+    def forward(ctx, y, lens, relu, *scales):
+        y = _c(y)
+        B, Tg, NC = y.shape
+        L = len(lens)
+        sc = [s.contiguous().view(1) for s in scales] if scales else None
+        out = torch.empty((B, Tg - L, NC), dtype=torch.float32, device=y.device)
+        check(lib.avdf_head_out_fwd(_p(y), _ptr_table(sc) if sc else None, _int_table(lens), L, _p(out), B, NC, int(relu),
+                                    _stream()), "head_out_fwd")
+        ctx.save_for_backward(y, out, *(sc or []))
+        ctx.cfg = (B, Tg, NC, list(lens), int(relu), [s.shape for s in scales])
+        ctx.main = [_main_grad(s) for s in scales]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, *sc = ctx.saved_tensors
+        B, Tg, NC, lens, relu, sshapes = ctx.cfg
+        L = len(lens)
+        dout = dout.contiguous()
+        dy = torch.empty_like(y)
+        acc = bool(sc) and all(m is not None for m in ctx.main)
+        ds = None
+        if sc:
+            ds = [m.view(1) for m in ctx.main] if acc else [torch.zeros(1, dtype=torch.float32, device=y.device) for _ in sc]
+        check(lib.avdf_head_out_bwd(_p(dout), _p(y), _p(out), _ptr_table(sc) if sc else None, _ptr_table(ds) if ds else None,
+                                    _int_table(lens), L, _p(dy), B, NC, relu, _stream()), "head_out_bwd")
+        gs = [None] * len(sc) if (acc or not sc) else [d.view(shp) for d, shp in zip(ds, sshapes)]
+        return (dy, None, None, *gs)
+
+
+def head_out(y, lens, relu=False, scales=()):
+    return HeadOutFn.apply(y, tuple(int(n) for n in lens), relu, *scales)
+
+
+@torch.no_grad()
+def mask_pyramid(mask, n_levels, stride=2):
+    """[B, T] -> n_levels masks, level l = mask[:, ::stride^(l+1)] (one launch)."""
+    mask = _c(mask)
+    B, T = mask.shape
+    outs, n = [], T
+    for _ in range(n_levels):
+        n //= stride
+        outs.append(torch.empty((B, n), dtype=torch.float32, device=mask.device))
+    check(lib.avdf_mask_pyramid(_p(mask), _ptr_table(outs), n_levels, B, T, stride, _stream()), "mask_pyramid")
+    return outs
+
+
+# --------------------------------------------------------------------------------------------
 # InstanceNorm + LeakyReLU, pooling
 # --------------------------------------------------------------------------------------------
 class InstNormLReluFn(torch.autograd.Function):

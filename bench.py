@@ -1,7 +1,8 @@
 """Headline benchmark: AV clips/s (768-frame) for one full training step (K1 interpolation ->
 UMMAFormer forward -> losses -> backward -> clipped AdamW + EMA) of the exp10 AV-fusion model on
 N MI355X GPUs of one node, one process per GPU, clip-level data parallel (weak scaling:
-8 clips per GPU per step).
+8 clips per GPU per step; gradient buckets all-reduced over RCCL while the next backward phase runs --
+the line's `data_parallel` object reports the exposed all-reduce time and the step time without overlap).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -24,6 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF)
 STREAMS = [(768, 256), (383, 2048), (1535, 768)]      # LAV-DF video, BYOL-A, Emotion2Vec of a 768-frame clip
 
 
@@ -55,29 +57,40 @@ def load_batch(eng, first_clip):
             eng.ngt[b] = n
 
 
+def _profile_file(stem):
+    """Newest committed PMC summary profiles/rNN_*_<stem>.json (collected by separate rocprofv3 --pmc passes, see
+    tools/pmc_summary.py / tools/pmc_mfma.py) -- these are STATIC artefacts of the commit named inside them, not a
+    measurement of this run; the bench line says so."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{stem}.json")))
+    return files[-1] if files else None
+
+
+def _norm_tag(tag):
+    return tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad").replace("bwdpair3", "bwdpair")
+
+
 def pmc_traffic(tag):
-    """HBM bytes per launch of the kernel class `tag`, from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
-    gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, separate passes; tools/pmc_summary.py) -- or None."""
-    path = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the kernel class `tag` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+    correction of MI355X_MICROARCH.md + WRITE_SIZE, separate passes) -- or None."""
+    path = _profile_file("pmc_traffic")
     try:
-        ent = json.load(open(path))["by_tag"].get(tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad").replace("bwdpair3", "bwdpair"))
-        return None if ent is None else {"bytes_per_launch": ent["bytes_per_launch"], "fetch_bytes": ent["fetch_bytes"],
-                                         "write_bytes": ent["write_bytes"], "source": "profiles/r01_i_pmc_traffic.json"}
+        d = json.load(open(path))
+        ent = d["by_tag"][_norm_tag(tag)]
+        return {"bytes_per_launch": ent["bytes_per_launch"], "fetch_bytes": ent["fetch_bytes"], "write_bytes": ent["write_bytes"],
+                "static": True, "source": os.path.relpath(path, ROOT), "measured_at_commit": d.get("commit", "round-1 build")}
     except Exception:
         return None
 
 
 def pmc_mfma_util(tag):
     """MFMA-pipe utilisation of the kernel class `tag` (SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x un-instrumented
-    launch duration x 2.4 GHz); tools/pmc_mfma.py) from the committed PMC pass -- or None."""
-    path = os.path.join(ROOT, "profiles", "r01_i_pmc_mfma_util.json")
+    launch duration x 2.4 GHz)) from the committed PMC pass -- or None."""
+    path = _profile_file("pmc_mfma_util")
     try:
         d = json.load(open(path))
-        tag = tag.replace("fwd3", "fwd").replace("dgrad3", "dgrad").replace("bwdpair3", "bwdpair")
-        return {"kernel": d["by_tag"][tag]["mfma_util"], "all_conv_kernels": d["all_conv_kernels"],
-                "source": "profiles/r01_i_pmc_mfma_util.json"}
+        return {"kernel": d["by_tag"][_norm_tag(tag)]["mfma_util"], "all_conv_kernels": d["all_conv_kernels"], "static": True,
+                "source": os.path.relpath(path, ROOT), "measured_at_commit": d.get("commit", "round-1 build")}
     except Exception:
         return None
 
@@ -119,6 +132,58 @@ def cpu_baseline(batch, budget_s=15.0):
     return {"value": round(done * batch / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": f"{done} fwd+bwd steps of {batch} exp10 clips (T=768, C_in=3072, fp32; K1 interpolation and the optimiser "
                       f"step are NOT in the CPU timing) in {el:.1f}s on {threads} threads"}
+
+
+def cpu_baseline_infer(budget_s=15.0):
+    """CPU oracle of the inference path (K1 -> forward -> decode -> NMS, one clip per call like inference.py) on a bounded
+    sample: clips until ~budget_s seconds elapsed."""
+    from oracle import ummaformer_ref as R
+    cfg = R.make_cfg(input_dim=sum(c for _, c in STREAMS))
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    sd = R.synth_state_dict(R.param_shapes(cfg), 0, trained_like=False)
+    done, t0 = 0, time.time()
+    while True:
+        feats, _ = synth_clip(done)
+        x = R.interp_concat([f.numpy() for f in feats], 768, always=(False,) + (True,) * (len(feats) - 1)
+                            if len(feats) > 1 else (True,))
+        R.infer_clip(sd, cfg, x)
+        done += 1
+        el = time.time() - t0
+        if el > budget_s or done >= 200:
+            break
+    return {"value": round(done / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{done} clips (K1 interpolation + exp10 forward + decode + NMS, fp32) in {el:.1f}s on {threads} threads"}
+
+
+def cpu_baseline_e2e(frames_per_sample=24):
+    """CPU oracles of the raw-media path on a SHORT sample (C3D alone is 3.5 TFLOP per 768-frame clip: minutes on the host):
+    one clip of `frames_per_sample` frames at 224x224 + the matching 16 kHz audio through the three encoder restatements,
+    scaled linearly to 768 frames (every encoder is linear in clip length but the Emotion2Vec attention, which is
+    quadratic -- the scaling flatters the CPU), plus one full-length localisation pass."""
+    from oracle import byola_ref as BR, c3d_ref as CR, emotion2vec_ref as ER
+    from audio_visual_deepfake_detection_amd.extractors import AudioNTT2020Task6, Emotion2Vec, C3DVideoEncoder
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(7)
+    sd_b = AudioNTT2020Task6().eval().state_dict()
+    sd_e = Emotion2Vec().state_dict()
+    sd_c = C3DVideoEncoder().state_dict()
+    g = torch.Generator().manual_seed(3000)
+    n = frames_per_sample
+    pcm = torch.rand(int(n / 25.0 * 16000), generator=g) - 0.5
+    frames = torch.randint(0, 256, (n, 224, 224, 3), generator=g, dtype=torch.uint8)
+    t0 = time.time()
+    with torch.no_grad():
+        CR.video_features(sd_c, frames, chunk=n + 8)                 # one chunk of n + 8 frames (the product's tail trim)
+        BR.byola_forward(sd_b, BR.log_mel(pcm)[None, None])
+        ER.forward(sd_e, pcm[None])
+    t_enc = (time.time() - t0) * 768.0 / n
+    loc = cpu_baseline_infer(budget_s=3.0)
+    t_clip = t_enc + 1.0 / loc["value"]
+    return {"value": round(1.0 / t_clip, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"encoder restatements (C3D + log-mel/BYOL-A + Emotion2Vec, fp32) on one {n}-frame clip scaled x{768 // n} to "
+                      f"768 frames ({t_enc:.1f}s per clip) + the localisation oracle ({1.0 / loc['value']:.2f}s per clip), {threads} threads"}
 
 
 def main():
@@ -170,7 +235,7 @@ def main():
 
     ops.BRANCH_STREAMS = args.branch_streams
     ops.INFER_BF16X3 = bool(args.bf16x3)
-    torch.manual_seed(0)                       # identical random-init weights on every rank
+    torch.manual_seed(rank)                    # per-rank init on purpose: TrainStep broadcasts rank 0's weights (dp.broadcast_params_)
     global STREAMS
     if args.workload == "audio":
         assert args.mode != "e2e", "--workload audio has no raw-media mode"
@@ -207,7 +272,9 @@ def main():
                         use_graph=not args.no_graph, process_group=pg, wgrad_side=args.wgrad_side, fwd_bf16x3=args.bf16x3_fwd)
     else:
         eng = InferStep(model, B, STREAMS, use_graph=not args.no_graph, bf16x3=args.bf16x3)
-    load_batch(eng, rank * B)
+    from audio_visual_deepfake_detection_amd import dp
+    first_clip, _ = dp.shard_range(world * B, rank, world)            # clip ids of this rank's shard of the global batch
+    load_batch(eng, first_clip)
     eng.capture()
 
     def barrier():
@@ -234,50 +301,89 @@ def main():
     dt = float(tmax.item())
     clips_per_s = world * B * args.steps / dt
 
+    # ---- data-parallel exchange: how much of it is exposed ---------------------------------------------
+    comm = None
+    if world > 1 and args.mode == "train":
+        def timed_steps(n):
+            barrier()
+            t = time.perf_counter()
+            for _ in range(n):
+                eng.step()
+            barrier()
+            return (time.perf_counter() - t) / n * 1e3
+        eng.comm_events = ()
+        exposed = []
+        for _ in range(5):
+            eng.comm_events = ()
+            eng.step()
+            torch.cuda.synchronize()
+            exposed.append(eng.comm_events[0].elapsed_time(eng.comm_events[1]))
+        eng.comm_events = None
+        eng.overlap = False
+        serial_ms = timed_steps(max(5, args.steps // 2))
+        eng.overlap = True
+        comm = {"grad_bytes": int(eng.flat_g.numel() * 4),
+                "buckets_mb": [round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in eng.bucket_ranges],
+                "allreduce_exposed_ms_per_step": round(float(np.median(exposed)), 3),
+                "ms_per_step_overlapped": round(dt / args.steps * 1e3, 3), "ms_per_step_not_overlapped": round(serial_ms, 3)}
+
     # ---- roofline pass: the same step, eager, HIP events around every MFMA conv launch -----------
     # A GPU-side spin is queued first so that the host has enqueued the whole step before the first kernel runs:
     # the events then bracket back-to-back GPU execution (no host launch gaps inside the brackets).
     roof = None
+    bf3 = (args.mode != "train" and args.bf16x3)
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if bf3 else PEAK_F32_MFMA_TFLOPS
     if args.mode == "train":
         use_graph = eng.use_graph
         graphs, eng.graphs, eng.use_graph = eng.graphs, None, False
-        eng.step()                      # eager warm-up
+        run_eager = eng.step
+    else:
+        graphs, eng.graph = eng.graph, None
+        run_eager = one_step
+    run_eager()                      # eager warm-up
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(1000000)
+    e1.record()
+    torch.cuda.synchronize()
+    spin = int(60.0 / max(e0.elapsed_time(e1), 1e-3) * 1000000)       # ~60 ms worth of spin cycles
+    ops.profile_begin()
+    nprof = 3 if args.mode != "e2e" else 1
+    for _ in range(nprof):
+        torch.cuda._sleep(spin)
+        run_eager()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        torch.cuda._sleep(1000000)
-        e1.record()
-        torch.cuda.synchronize()
-        spin = int(60.0 / max(e0.elapsed_time(e1), 1e-3) * 1000000)       # ~60 ms worth of spin cycles
-        ops.profile_begin()
-        nprof = 3
-        for _ in range(nprof):
-            torch.cuda._sleep(spin)
-            eng.step()
-            torch.cuda.synchronize()
-        recs = ops.profile_end()
+    recs = ops.profile_end()
+    if args.mode == "train":
         eng.graphs, eng.use_graph = graphs, use_graph
-        agg = {}
-        for tag, fl, s, e in recs:
-            a = agg.setdefault(tag, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += s.elapsed_time(e) * 1e-3
-            a[2] += fl
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
-        tot_t = sum(v[1] for v in agg.values())
-        tot_f = sum(v[2] for v in agg.values())
-        tag, (cnt, tsec, fl) = dom
-        ach = fl / tsec / 1e12
-        roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(tag),
-                "mfma_util": pmc_mfma_util(tag), "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
-                "flops_per_launch": round(fl / cnt),
-                "all_conv_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2),
-                                     "frac": round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                     "ms_per_step": round(tot_t / nprof * 1e3, 3)},
-                "per_kernel": {k: {"n": v[0] // nprof, "ms_per_step": round(v[1] / nprof * 1e3, 3),
-                                   "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(agg.items())}}
+    else:
+        eng.graph = graphs
+    agg = {}
+    for tag, fl, s, e in recs:
+        a = agg.setdefault(tag, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += s.elapsed_time(e) * 1e-3
+        a[2] += fl
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    tot_t = sum(v[1] for v in agg.values())
+    tot_f = sum(v[2] for v in agg.values())
+    tag, (cnt, tsec, fl) = dom
+    ach = fl / tsec / 1e12
+    roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(peak, 1),
+            "peak_note": ("bf16 dense MFMA peak / 3 (three bf16 MFMAs per product in bf16x3 mode)" if bf3 else
+                          "f32-input MFMA dense peak (the arithmetic the path computes in)"),
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": pmc_traffic(tag) if args.mode == "train" else None,
+            "mfma_util": pmc_mfma_util(tag) if args.mode == "train" else None,
+            "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
+            "flops_per_launch": round(fl / cnt),
+            "all_mfma_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "frac": round(tot_f / tot_t / 1e12 / peak, 4),
+                                 "ms_per_step": round(tot_t / nprof * 1e3, 3)},
+            "per_kernel": {k: {"n": v[0] // nprof, "ms_per_step": round(v[1] / nprof * 1e3, 3),
+                               "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(agg.items())}}
 
+    losses = eng.losses() if args.mode == "train" else None          # a collective under DP: every rank calls it
     if rank == 0:
         line = {
             "metric": {"train": "AV clips/sec (768-frame) fwd+bwd", "infer": "AV clips/sec (768-frame) inference",
@@ -301,12 +407,16 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
-            fwd_bwd = 3 * conv_flops_per_clip() * clips_per_s / world / 1e12
-            line["step_mfma_frac"] = round(fwd_bwd / PEAK_F32_MFMA_TFLOPS, 4)
+            if args.mode == "train":
+                fwd_bwd = 3 * conv_flops_per_clip() * clips_per_s / world / 1e12
+                line["step_mfma_frac"] = round(fwd_bwd / PEAK_F32_MFMA_TFLOPS, 4)
+        if comm is not None:
+            line["data_parallel"] = comm
         if args.mode == "train":
-            line["losses"] = eng.losses()
-        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
-            line["cpu_baseline"] = cpu_baseline(2)
+            line["losses"] = losses
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = (cpu_baseline(2) if args.mode == "train" else
+                                    cpu_baseline_infer() if args.mode == "infer" else cpu_baseline_e2e())
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -376,6 +376,28 @@ int avdf_video_prep(const uint8_t* frames, float* out, int T, int H0, int W0, in
 /* [N, H, W, C] -> [N, H/p, W/p, C] max over p x p windows (floor mode) */
 int avdf_maxpool_hw(const float* x, float* y, int64_t N, int H, int W, int C, int p, void* stream);
 
+/* ---- pyramid glue (replaces torch.cat / index_select / relu / mul and their autograd backward on the heads' path;
+ * av_fd_no_recon.py:75-89,144-159; Scale: blocks.py:1374-1392; mask down-sampling: blocks.py:51-55) ----------------
+ * Gapped sequence of n_levels (<= 8) pyramid levels: level l (lens[l] rows) is followed by ONE all-zero row, the zero
+ * padding of that level's k3 convs, so the shared heads run once over [B, sum(lens) + n_levels, C].
+ * x / masks / dx / scale / dscale are HOST arrays of n_levels device pointers.                                  */
+int avdf_gap_concat_fwd(const float* const* x /*[B,lens[l],C]*/, const float* const* masks /*[B,lens[l]] or NULL*/,
+                        const int* lens, int n_levels, float* out /*[B,Tg,C]*/, float* mask_out /*[B,Tg] or NULL*/,
+                        int B, int C, void* stream);
+int avdf_gap_concat_bwd(const float* dout, float* const* dx /*NULL entries are skipped*/, const int* lens, int n_levels,
+                        int B, int C, void* stream);
+/* Compaction of a head output on the gapped sequence to point order [B, P, NC] (P = sum lens), with the regression
+ * head's per-level Scale and ReLU: out = relu?(y * scale_l[0]).  scale == NULL: plain compaction (cls head).
+ * bwd: dy (gap rows 0) and, when given, dscale_l[0] += sum dout * [out > 0] * y (atomics: dscale accumulates).     */
+int avdf_head_out_fwd(const float* y /*[B,Tg,NC]*/, const float* const* scale, const int* lens, int n_levels,
+                      float* out, int B, int NC, int relu, void* stream);
+int avdf_head_out_bwd(const float* dout, const float* y, const float* out, const float* const* scale,
+                      float* const* dscale, const int* lens, int n_levels, float* dy, int B, int NC, int relu,
+                      void* stream);
+/* out[l][b, t] = mask[b, t * stride^(l+1)], l = 0 .. n_levels-1: every pyramid mask of a forward in one launch */
+int avdf_mask_pyramid(const float* mask /*[B,T]*/, float* const* out, int n_levels, int B, int T, int stride,
+                      void* stream);
+
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);
 int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);

@@ -697,6 +697,7 @@ def main():
     case_tinydataset(ctx)
     case_forward("fwd_audio_exp10", R.make_cfg(**AUDIO_EXP10), [768, 601], 81, 82, ctx)
     case_train("train_audio_exp10", R.make_cfg(**AUDIO_EXP10), [768, 700, 768, 650], 81, 83, ctx)
+    case_train_f64("train_audio_exp10_f64", "train_audio_exp10", R.make_cfg(**AUDIO_EXP10))
     case_forward("fwd_exp5", R.make_cfg(**EXP5), [768, 655], 91, 92, ctx)
     case_train("train_exp5", R.make_cfg(**EXP5), [768, 700, 640], 91, 93, ctx)
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
@@ -706,6 +707,7 @@ def main():
     case_train("train_mid", R.make_cfg(**MID), [384, 300, 350, 200], 7, 10, ctx)
     case_forward("fwd_exp10", R.make_cfg(), [768, 700], 21, 22, ctx)
     case_train("train_exp10", R.make_cfg(), [768, 700, 768, 650], 21, 23, ctx)          # full-size exp10, 4 clips
+    case_train_f64("train_exp10_f64", "train_exp10", R.make_cfg())
     case_forward("fwd_the_small", R.make_cfg(variant="the", **SMALL), [192, 133], 31, 32, ctx)
     case_train("train_the_small", R.make_cfg(variant="the", **SMALL), [192, 150, 180, 192], 33, 34, ctx)
     case_forward("fwd_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 151], 51, 52, ctx)
@@ -780,11 +782,44 @@ def case_eval_detection():
     np.savez_compressed(os.path.join(GOLD, "eval_detection.npz"), **out)
 
 
+def case_train_f64(name, base, cfg, ctx=None):
+    """float64 ground truth for the gradient elements the fp32 fixtures hold loosest (the DeepInterpolator convs that feed an
+    InstanceNorm over time): the oracle -- pinned to the reference in fp32 by `base` -- re-run in float64 on the same weights /
+    inputs / targets.  Stores the fp64 sample of every `contraction.down_*` gradient of `base` next to the error of the
+    REFERENCE's own fp32 gradient against it, i.e. the conditioning any fp32 implementation lives with."""
+    g = np.load(os.path.join(GOLD, f"{base}.npz"), allow_pickle=True)
+    lens = [int(v) for v in g["lens"]]
+    x, mask = synth_inputs(cfg, lens, int(g["xseed"]))
+    sd = R.synth_state_dict(R.param_shapes(cfg), int(g["wseed"]), True)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    gts = [torch.from_numpy(np.asarray(s_, np.float32)).double() if f else None for s_, f in zip(g["gt_segments"], g["is_fake"])]
+    gls = [None if s_ is None else torch.zeros(len(s_), dtype=torch.int64) for s_ in gts]
+    out = R.model_forward(sd64, cfg, x.double(), mask.double(), training=True)
+    ol, norm, _ = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], x_in=x.double())
+    ol["final_loss"].backward()
+    store = {"base": np.array(base), "final_loss": np.array(float(ol["final_loss"]))}
+    print(f"[{name}] fp64 final_loss {float(ol['final_loss']):.9f} (fp32 reference: {float(g['losses'][3]):.9f})")
+    for key in g.files:
+        if not key.startswith("grad::") or "contraction.down_" not in key:
+            continue
+        flat = sd64[key[6:]].grad.flatten()
+        stride = max(1, flat.numel() // 4096)
+        ref64 = flat[::stride][:4096].numpy().copy()
+        ref32 = g[key].astype(np.float64)
+        e = float(np.abs(ref32 - ref64).max() / (np.abs(ref64).max() + 1e-300))
+        store["grad64::" + key[6:]] = ref64
+        store["referr::" + key[6:]] = np.array(e)
+        print(f"[{name}] {key[6:]}: reference fp32 vs fp64 ground truth, max rel. element error {e:.3e}")
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **store)
+
+
 NAMED = {
     "metrics": lambda ctx: case_metrics(),
     "nms_modes": lambda ctx: case_nms_modes(),
     "lr": lambda ctx: case_lr_schedules(),
     "eval_detection": lambda ctx: case_eval_detection(),
+    "train_f64": lambda ctx: (case_train_f64("train_exp10_f64", "train_exp10", R.make_cfg()),
+                              case_train_f64("train_audio_exp10_f64", "train_audio_exp10", R.make_cfg(**AUDIO_EXP10))),
     "byola_net": lambda ctx: case_byola_net(),
     "emotion2vec_parts": lambda ctx: case_emotion2vec_parts(),
     "optimizer_split": case_optimizer_split,

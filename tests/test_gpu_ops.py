@@ -637,3 +637,65 @@ def test_conv1d_residual_matches_separate_ops(ops, B, T, Cin, Cout, use_keep, ma
         fused = ops.conv1d_residual(dl[0], dl[1], dl[2], None if mask is None else g32(mask), dl[3], dl[4],
                                     None if keep is None else g32(keep))
     close(fused, sep.double().cpu(), "fused vs separate", rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# pyramid glue (csrc/glue.hip): gapped level sequence, head-output compaction with Scale + ReLU, mask pyramid
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,lens", [(2, 32, [48, 24, 12]), (3, 256, [768, 384, 192, 96, 48, 24]), (1, 8, [5])])
+def test_gap_concat_matches_cat_with_zero_rows(ops, B, C, lens):
+    xs = [rnd(B, n, C, seed=10 + i) for i, n in enumerate(lens)]
+    ms = [mk_mask(B, n, [n - (b % 3) for b in range(B)]) for n in lens]
+    xg = [g32(x, True) for x in xs]
+    out, gmask = ops.gap_concat(xg, [g32(m) for m in ms])
+    z, zm = torch.zeros(B, 1, C, dtype=torch.float64), torch.zeros(B, 1, dtype=torch.float64)
+    ref = torch.cat([t for x in xs for t in (x, z)], dim=1)
+    refm = torch.cat([t for m in ms for t in (m, zm)], dim=1)
+    close(out, ref, "gap_concat", rtol=0)
+    close(gmask, refm, "gap mask", rtol=0)
+    w = rnd(*ref.shape, seed=99)
+    (out * g32(w)).sum().backward()
+    off = 0
+    for x, n in zip(xg, lens):
+        close(x.grad, w[:, off:off + n], "gap_concat bwd", rtol=0)
+        off += n + 1
+
+
+@pytest.mark.parametrize("B,NC,lens,relu", [(2, 2, [48, 24, 12], True), (8, 2, [768, 384, 192, 96, 48, 24], True),
+                                            (3, 1, [96, 48], False)])
+def test_head_out_matches_index_select_scale_relu(ops, B, NC, lens, relu):
+    Tg = sum(lens) + len(lens)
+    y = rnd(B, Tg, NC, seed=3)
+    sc = [1.0 + 0.2 * float(rnd(1, seed=40 + l)) for l in range(len(lens))] if relu else None
+    idx, rs, off = [], [], 0
+    for l, n in enumerate(lens):
+        idx.append(torch.arange(off, off + n))
+        rs += [sc[l] if sc else 1.0] * (n + 1)
+        off += n + 1
+    idx = torch.cat(idx)
+    yr = y.clone().requires_grad_(True)
+    scr = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in sc] if sc else []
+    if sc:
+        rvec = torch.cat([s.reshape(1).expand(n + 1) for s, n in zip(scr, lens)])
+        ref = torch.relu(yr * rvec[None, :, None]).index_select(1, idx)
+    else:
+        ref = yr.index_select(1, idx)
+    yg = g32(y, True)
+    scg = [torch.tensor(v, dtype=torch.float32, device=dev(), requires_grad=True) for v in sc] if sc else []
+    out = ops.head_out(yg, lens, relu=relu, scales=scg)
+    close(out, ref, "head_out")
+    w = rnd(*ref.shape, seed=5)
+    (ref * w).sum().backward()
+    (out * g32(w)).sum().backward()
+    close(yg.grad, yr.grad, "head_out dy")
+    for a, b in zip(scg, scr):
+        close(a.grad.reshape(1), b.grad.reshape(1), "head_out dscale", rtol=1e-4)
+
+
+def test_mask_pyramid_equals_strided_slices(ops):
+    m = mk_mask(4, 768, [768, 700, 1, 333])
+    outs = ops.mask_pyramid(g32(m), 5, 2)
+    cur = m
+    for o in outs:
+        cur = cur[:, ::2]
+        close(o, cur, "mask pyramid", rtol=0)
