@@ -75,8 +75,15 @@ __global__ __launch_bounds__(256) void adamw_ema_seg_kernel(float* __restrict__ 
   const float step = lr / bias_c1;
   const float inv_sqrt_c2 = 1.f / sqrtf(bias_c2);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float wd = seg.wd[seg.n - 1];
-    for (int s_ = 0; s_ < seg.n; ++s_) if (i < seg.end[s_]) { wd = seg.wd[s_]; break; }
+    // compile-time indices only (a run-time index into the by-value struct would put it in scratch memory)
+    float wd = 0.f;
+    bool found = false;
+#pragma unroll
+    for (int s_ = 0; s_ < kMaxSeg; ++s_) {
+      const bool hit = !found && s_ < seg.n && i < seg.end[s_];
+      wd = hit ? seg.wd[s_] : wd;
+      found = found || hit;
+    }
     const float gi = g[i] * cs;
     float pi = p[i] * (1.f - lr * wd);
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;

@@ -1027,6 +1027,7 @@ class GapConcatFn(torch.autograd.Function):
                                       _stream()), "gap_concat_fwd")
         ctx.cfg = (B, C, lens)
         ctx.mark_non_differentiable(gmask)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for the mask output
         return out, gmask
 
     @staticmethod
