@@ -67,10 +67,13 @@ class ConvHRLRFullResSelfAttTransformerBackboneRevised(nn.Module):
             x, mask = self.embd[idx](x, mask)
             pe = None
             if idx == last and self.use_abs_pe:
-                # training: fixed-length table; eval: table re-interpolated only when T > max_len
-                # (backbones.py:447-465) -- force_upsampling keeps T == max_len, where both coincide
-                assert T <= self.max_len, "Reached max length."
-                pe = self.pos_embd_tm[:T]
+                # training: fixed-length table; eval: table linearly re-interpolated to T rows when T >= max_len
+                # (backbones.py:447-465; identity at T == max_len) -- the K1 kernel is that interpolation
+                if self.training or T <= self.max_len:
+                    assert T <= self.max_len, "Reached max length."
+                    pe = self.pos_embd_tm[:T]
+                else:
+                    pe = ops.interp_concat([self.pos_embd_tm], T)
             x = self.embd_norm[idx](x, relu=True, pe=pe, mask=mask if pe is not None else None)
         return x
 

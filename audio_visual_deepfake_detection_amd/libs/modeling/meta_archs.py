@@ -264,9 +264,13 @@ class AVPtTransformerRecovery(nn.Module):
         else:
             assert len(video_list) == 1 or getattr(self, "allow_batched_eval", False), \
                 "Only support batch_size = 1 during inference"
-            assert max_len <= self.max_seq_len, \
-                "force_upsampling keeps T <= max_seq_len; longer inputs are not supported on the HIP path yet"
-            max_len = self.max_seq_len
+            if max_len <= self.max_seq_len:
+                max_len = self.max_seq_len
+            else:
+                # longer than max_seq_len: pad to the next length every pyramid level / attention window divides
+                # (av_fd_no_recon.py:458-463); needs max_buffer_len_factor > 1 for the point generator, as in the reference
+                stride = self.max_div_factor
+                max_len = (max_len + (stride - 1)) // stride * stride
         B, C = len(video_list), self.input_dim
         if tm:
             x = torch.full((B, max_len, C), padding_val, dtype=torch.float32, device=dev)

@@ -700,6 +700,7 @@ def main():
     case_train_f64("train_audio_exp10_f64", "train_audio_exp10", R.make_cfg(**AUDIO_EXP10))
     case_forward("fwd_exp5", R.make_cfg(**EXP5), [768, 655], 91, 92, ctx)
     case_train("train_exp5", R.make_cfg(**EXP5), [768, 700, 640], 91, 93, ctx)
+    case_train_f64("train_exp5_f64", "train_exp5", R.make_cfg(**EXP5))
     case_forward("fwd_small", R.make_cfg(**SMALL), [192, 150], 3, 4, ctx)
     case_forward("fwd_small_init", R.make_cfg(**SMALL), [192, 101], 5, 6, ctx, trained_like=False)
     case_forward("fwd_mid", R.make_cfg(**MID), [384, 300, 97], 7, 8, ctx)
@@ -783,10 +784,9 @@ def case_eval_detection():
 
 
 def case_train_f64(name, base, cfg, ctx=None):
-    """float64 ground truth for the gradient elements the fp32 fixtures hold loosest (the DeepInterpolator convs that feed an
-    InstanceNorm over time): the oracle -- pinned to the reference in fp32 by `base` -- re-run in float64 on the same weights /
-    inputs / targets.  Stores the fp64 sample of every `contraction.down_*` gradient of `base` next to the error of the
-    REFERENCE's own fp32 gradient against it, i.e. the conditioning any fp32 implementation lives with."""
+    """float64 ground truth for the sampled gradients of a full-size training fixture: the oracle -- pinned to the reference
+    in fp32 by `base` -- re-run in float64 on the same weights / inputs / targets.  Stores the fp64 sample of every gradient of
+    `base` next to the error of the REFERENCE's own fp32 gradient against it, i.e. what fp32 rounding alone costs."""
     g = np.load(os.path.join(GOLD, f"{base}.npz"), allow_pickle=True)
     lens = [int(v) for v in g["lens"]]
     x, mask = synth_inputs(cfg, lens, int(g["xseed"]))
@@ -800,7 +800,7 @@ def case_train_f64(name, base, cfg, ctx=None):
     store = {"base": np.array(base), "final_loss": np.array(float(ol["final_loss"]))}
     print(f"[{name}] fp64 final_loss {float(ol['final_loss']):.9f} (fp32 reference: {float(g['losses'][3]):.9f})")
     for key in g.files:
-        if not key.startswith("grad::") or "contraction.down_" not in key:
+        if not key.startswith("grad::"):
             continue
         flat = sd64[key[6:]].grad.flatten()
         stride = max(1, flat.numel() // 4096)
@@ -819,7 +819,8 @@ NAMED = {
     "lr": lambda ctx: case_lr_schedules(),
     "eval_detection": lambda ctx: case_eval_detection(),
     "train_f64": lambda ctx: (case_train_f64("train_exp10_f64", "train_exp10", R.make_cfg()),
-                              case_train_f64("train_audio_exp10_f64", "train_audio_exp10", R.make_cfg(**AUDIO_EXP10))),
+                              case_train_f64("train_audio_exp10_f64", "train_audio_exp10", R.make_cfg(**AUDIO_EXP10)),
+                              case_train_f64("train_exp5_f64", "train_exp5", R.make_cfg(**EXP5))),
     "byola_net": lambda ctx: case_byola_net(),
     "emotion2vec_parts": lambda ctx: case_emotion2vec_parts(),
     "optimizer_split": case_optimizer_split,

@@ -137,18 +137,20 @@ def test_oracle_on_tinydataset_items_matches_reference(tmp_path, golden_dir):
         assert float((o["scores"][perm] - torch.from_numpy(g["scores"][i][:k])).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["train_exp10_f64", "train_audio_exp10_f64"])
-def test_reference_fp32_gradients_sit_on_the_float64_ground_truth(golden_dir, name):
-    """tests/golden/*_f64.npz: the oracle re-run in float64 is the ground truth of the loosest-held gradient elements
-    (DeepInterpolator convs); the REFERENCE's own fp32 gradient sample lies within 1e-5 of it, so those elements are NOT
-    ill-conditioned in general -- the GPU suite shows the HIP deviations are isolated LeakyReLU-derivative flips
-    (tests/test_gpu_model.py::test_interpolator_gradient_differences_are_leaky_relu_flips)."""
+@pytest.mark.parametrize("name,bound", [("train_exp10_f64", 1e-4), ("train_audio_exp10_f64", 1e-4), ("train_exp5_f64", 2e-2)])
+def test_reference_fp32_gradients_against_float64_ground_truth(golden_dir, name, bound):
+    """tests/golden/*_f64.npz: the oracle re-run in float64 is the ground truth of every sampled gradient of the full-size
+    training fixtures; `referr::*` records how far the REFERENCE's own fp32 gradient sample lies from it.  exp10: <= 1e-4
+    everywhere (1.3e-6 on the DeepInterpolator convs -- the HIP deviations there are isolated LeakyReLU-derivative flips,
+    tests/test_gpu_model.py::test_interpolator_gradient_differences_are_leaky_relu_flips).  exp5: the L1 reconstruction
+    loss and the Expansion's kinks make the reference itself up to 1e-2 inexact on some tensors -- the GPU tolerance of
+    those tensors is tied to these numbers."""
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
     base = np.load(os.path.join(golden_dir, f"{str(g['base'])}.npz"), allow_pickle=True)
     keys = [k for k in g.files if k.startswith("grad64::")]
-    assert keys
+    assert len(keys) >= 13
     for k in keys:
         ref32 = base["grad::" + k[8:]].astype(np.float64)
         e = float(np.abs(ref32 - g[k]).max() / np.abs(g[k]).max())
-        assert e < 1e-5 and abs(e - float(g["referr::" + k[8:]])) < 1e-12, (k, e)
+        assert e < bound and abs(e - float(g["referr::" + k[8:]])) < 1e-12, (k, e)
     assert abs(float(g["final_loss"]) - float(base["losses"][3])) < 1e-6
