@@ -107,6 +107,7 @@ SIGNATURES = {
     "avdf_head_out_fwd": (I, [P, P, P, I, P, I, I, I, P]),
     "avdf_head_out_bwd": (I, [P, P, P, P, P, P, I, P, I, I, I, P]),
     "avdf_mask_pyramid": (I, [P, P, I, I, I, I, P]),
+    "avdf_keep_from_uniform": (I, [P, P, P, L, I, I, F, P]),
     "avdf_sumsq_ws": (L, []),
     "avdf_sumsq": (I, [P, P, P, L, P]),
     "avdf_adamw_ema": (I, [P, P, P, P, P, P, P, L, F, F, F, F, F, F, P]),

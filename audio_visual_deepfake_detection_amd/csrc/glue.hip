@@ -120,6 +120,21 @@ __global__ __launch_bounds__(256) void mask_pyramid_kernel(const float* __restri
   }
 }
 
+// stochastic-depth / dropout keep factors from uniform draws u in [0, 1):
+//   mode 0 (AffineDropPath, blocks.py:1403-1409): out[r, b] = floor(keep_prob[r] + u[r, b]) / keep_prob[r]
+//   mode 1 (nn.Dropout(p)):                          out[i]    = u[i] >= p ? 1 / (1 - p) : 0
+__global__ __launch_bounds__(256) void keep_from_uniform_kernel(const float* __restrict__ u, const float* __restrict__ kp,
+                                                                float* __restrict__ out, long n, int cols, int mode, float p) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (mode == 0) {
+      const float k = kp[i / cols];
+      out[i] = floorf(k + u[i]) / k;
+    } else {
+      out[i] = u[i] >= p ? 1.f / (1.f - p) : 0.f;
+    }
+  }
+}
+
 inline int grid_for(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -218,5 +233,16 @@ extern "C" int avdf_mask_pyramid(const float* mask, float* const* out, int n_lev
   }
   hipLaunchKernelGGL(mask_pyramid_kernel, dim3(cdiv(T / stride, 256), B), dim3(256), 0, (hipStream_t)stream, mask, po, L, B, T);
   AVDF_CHECK_LAUNCH("mask_pyramid");
+  return AVDF_OK;
+}
+
+extern "C" int avdf_keep_from_uniform(const float* u, const float* keep_prob, float* out, int64_t n, int cols, int mode, float p,
+                                      void* stream) {
+  AVDF_REQUIRE(u && out && n > 0 && cols > 0 && (mode == 0 || mode == 1), "keep_from_uniform: bad args");
+  AVDF_REQUIRE(mode == 1 || keep_prob, "keep_from_uniform: drop-path mode needs the per-row keep probabilities");
+  AVDF_REQUIRE(mode == 0 || (p >= 0.f && p < 1.f), "keep_from_uniform: dropout p in [0, 1)");
+  hipLaunchKernelGGL(keep_from_uniform_kernel, dim3(grid_for((long)n)), dim3(256), 0, (hipStream_t)stream, u, keep_prob, out, (long)n,
+                     cols, mode, p);
+  AVDF_CHECK_LAUNCH("keep_from_uniform");
   return AVDF_OK;
 }

@@ -160,7 +160,7 @@ def plan_drop_path(root, batch, device):
         cache = (key, torch.tensor([1.0 - q for q in key], dtype=torch.float32, device=device)[:, None])
         root._drop_path_kp = cache
     kp = cache[1]
-    keep = (kp + torch.rand((len(mods), batch), dtype=torch.float32, device=device)).floor_() / kp
+    keep = ops.droppath_keep(torch.rand((len(mods), batch), dtype=torch.float32, device=device), kp)
     for i, m in enumerate(mods):
         m._planned_keep = keep[i]
 
@@ -528,7 +528,7 @@ class DeepInterpolator(nn.Module):
         h = ops.linear(pooled, self.conv1.weight)
         h = self.bn1(h, relu=True)
         if self.training and self.dp1.p > 0:
-            keep = (torch.rand_like(h) >= self.dp1.p).to(h.dtype) / (1.0 - self.dp1.p)
+            keep = ops.dropout_keep(torch.rand_like(h), self.dp1.p)
             h = ops.scale_rows(h.reshape(-1, 1), keep.reshape(-1)).view_as(h)
         w = self.conv2.weight
         return ops.smallconv(h.view(B, 1, -1), ops.view_param(w, (w.shape[0], w.shape[1], 1)),

@@ -1083,6 +1083,25 @@ def head_out(y, lens, relu=False, scales=()):
 
 
 @torch.no_grad()
+def droppath_keep(u, keep_prob):
+    """u [n_modules, B] uniform draws, keep_prob [n_modules] -> floor(kp + u) / kp (blocks.py:1403-1409), one launch."""
+    u = _c(u)
+    out = torch.empty_like(u)
+    check(lib.avdf_keep_from_uniform(_p(u), _p(_c(keep_prob).view(-1)), _p(out), u.numel(), int(u.shape[-1]), 0, 0.0, _stream()),
+          "keep_from_uniform")
+    return out
+
+
+@torch.no_grad()
+def dropout_keep(u, p):
+    """u uniform draws -> (u >= p) / (1 - p): the keep mask of nn.Dropout(p), one launch."""
+    u = _c(u)
+    out = torch.empty_like(u)
+    check(lib.avdf_keep_from_uniform(_p(u), None, _p(out), u.numel(), 1, 1, float(p), _stream()), "keep_from_uniform")
+    return out
+
+
+@torch.no_grad()
 def mask_pyramid(mask, n_levels, stride=2):
     """[B, T] -> n_levels masks, level l = mask[:, ::stride^(l+1)] (one launch)."""
     mask = _c(mask)

@@ -398,6 +398,12 @@ int avdf_head_out_bwd(const float* dout, const float* y, const float* out, const
 int avdf_mask_pyramid(const float* mask /*[B,T]*/, float* const* out, int n_levels, int B, int T, int stride,
                       void* stream);
 
+/* Keep factors of stochastic depth / dropout from uniform draws u in [0,1) (the draws themselves stay torch's Philox
+ * stream, which is hipGraph-safe): mode 0 = AffineDropPath (blocks.py:1403-1409), out[r,b] = floor(keep_prob[r] +
+ * u[r,b]) / keep_prob[r] over n = rows x cols elements; mode 1 = nn.Dropout(p), out[i] = u[i] >= p ? 1/(1-p) : 0.  */
+int avdf_keep_from_uniform(const float* u, const float* keep_prob, float* out, int64_t n, int cols, int mode, float p,
+                           void* stream);
+
 /* ---- optimiser step on flat buffers (next-row: train_utils.py:65-144,247-269,306-316) ---- */
 int64_t avdf_sumsq_ws(void);
 int avdf_sumsq(const float* x, float* out /*[1], accumulates*/, float* ws, int64_t n, void* stream);

@@ -699,3 +699,13 @@ def test_mask_pyramid_equals_strided_slices(ops):
     for o in outs:
         cur = cur[:, ::2]
         close(o, cur, "mask pyramid", rtol=0)
+
+
+def test_keep_factors_from_uniform_draws(ops):
+    u = torch.rand(36, 8)
+    kp = torch.tensor([0.9] * 30 + [0.5] * 6)
+    got = ops.droppath_keep(u.to(dev()), kp.to(dev())[:, None])
+    ref = (kp[:, None] + u).floor() / kp[:, None]
+    assert torch.equal(got.cpu(), ref)
+    u2 = torch.rand(8, 256)
+    assert torch.equal(ops.dropout_keep(u2.to(dev()), 0.5).cpu(), (u2 >= 0.5).float() / 0.5)
