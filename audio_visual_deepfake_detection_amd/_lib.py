@@ -85,6 +85,7 @@ SIGNATURES = {
     "avdf_maxpool2x2": (I, [P, P, I, I, I, I, P]),
     "avdf_softnms1d_host": (I, [P, P, L, F, F, F, I, P, P, P]),
     "avdf_batched_nms_host": (I, [P, P, L, F, F, L, F, P, P, P, P]),
+    "avdf_flash_attn_alibi": (I, [P, P, P, P, P, I, I, I, I, I, L, F, P]),
     "avdf_wave_conv_c1": (I, [P, P, P, L, L, I, I, I, P]),
     "avdf_grouped_conv_pos": (I, [P, P, P, P, I, I, I, I, P]),
     "avdf_grouped_conv1d_fwd": (I, [P, P, P, P, I, I, I, I, P]),

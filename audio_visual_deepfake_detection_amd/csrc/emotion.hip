@@ -232,3 +232,171 @@ extern "C" int avdf_softmax_alibi_heads(float* scores, int H, int T, int ld, int
   AVDF_CHECK_LAUNCH("softmax_alibi_heads");
   return AVDF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused attention of AltAttention.forward (upstream/models/modules.py:280-322): softmax(q k^T * scale + alibi) v for
+// all heads of a layer in ONE launch, the [H, T, T] score matrix never leaves the chip (it was 113 MB per layer per
+// 768-frame clip: written by the QK^T GEMM, rewritten by the softmax, read by the PV GEMM).
+//
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), flash-style online softmax.  One workgroup = 2 waves = 64 queries of one
+// head; each wave owns 32 queries and walks the keys in tiles of 32:
+//   S^T = K Q^T      A = K tile from LDS [key][d], B = Q^T from registers     -> D rows = keys, cols = queries
+//       so the 16 accumulator registers of a lane are 16 keys of ONE query (lane & 31): the row max / row sum of the
+//       softmax are 16 in-register values + one xor-32 shuffle (the two lane halves hold different keys);
+//   O^T += V^T P^T   A = V^T from LDS, B = P^T: accumulator register s of the score tile IS the B operand of k-step s
+//       when the contraction visits the keys in the accumulator's own row order j(s, h) = (s&3) + 8(s>>2) + 4h
+//       (h = lane >> 5) -- the A operand reads V rows in that order, so P never moves between registers or through LDS.
+// ALiBi: + slope_h * -|i - j| (base.py:538-604, scaled per head by the clamped alibi_scale); keys >= T are masked.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kFaHD = 64;                 // head dim of every released checkpoint (768 / 12)
+constexpr int kFaLD = kFaHD + 1;          // odd LDS row stride: the per-lane ds_read_b32 operand fetches are conflict-free
+
+__global__ __launch_bounds__(128) void flash_attn_alibi_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, float* __restrict__ out,
+                                                               const float* __restrict__ slopes, int T, int ld, float scale,
+                                                               long clip_stride) {
+  __shared__ float Ks[2][32 * kFaLD];
+  __shared__ float Vs[2][32 * kFaLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y;
+  const size_t base = (size_t)blockIdx.z * clip_stride + (size_t)head * kFaHD;
+  q += base; k += base; v += base; out += base;
+  const int q0 = blockIdx.x * 64;
+  const int qi = q0 + w * 32 + li;                       // this lane's query row
+  const float slope = slopes ? slopes[head] : 0.f;
+
+  // ---- Q^T operand: qreg[s] = scale * Q[qi][2s + lh], staged through LDS (coalesced global reads) ----------------
+  float qreg[32];
+  {
+    float* Qs = &Ks[0][0];                               // 64 x 65 floats fit the two K buffers (2 x 32 x 65)
+    for (int e = tid; e < 64 * (kFaHD / 4); e += 128) {
+      const int r = e / (kFaHD / 4), c4 = e % (kFaHD / 4);
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q0 + r < T) t = *reinterpret_cast<const float4*>(q + (size_t)(q0 + r) * ld + c4 * 4);
+      float* d = Qs + r * kFaLD + c4 * 4;
+      d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qreg[s] = Qs[(w * 32 + li) * kFaLD + 2 * s + lh] * scale;
+    __syncthreads();
+  }
+
+  floatx16 o0, o1;                                       // O^T accumulators: d-block 0 / 1, rows = d, cols = queries
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+
+  const int ntiles = (T + 31) / 32;
+  float4 rk[4], rv[4];                                   // register prefetch of the next K / V tile (512 float4 each / 128 threads)
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 128, r = e / (kFaHD / 4), c4 = e % (kFaHD / 4);
+      const int row = kt * 32 + r;
+      rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rv[i] = rk[i];
+      if (row < T) {
+        rk[i] = *reinterpret_cast<const float4*>(k + (size_t)row * ld + c4 * 4);
+        rv[i] = *reinterpret_cast<const float4*>(v + (size_t)row * ld + c4 * 4);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 128, r = e / (kFaHD / 4), c4 = e % (kFaHD / 4);
+      float* dk = &Ks[buf][r * kFaLD + c4 * 4];
+      float* dv = &Vs[buf][r * kFaLD + c4 * 4];
+      dk[0] = rk[i].x; dk[1] = rk[i].y; dk[2] = rk[i].z; dk[3] = rk[i].w;
+      dv[0] = rv[i].x; dv[1] = rv[i].y; dv[2] = rv[i].z; dv[3] = rv[i].w;
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const float* Kb = Ks[buf];
+    const float* Vb = Vs[buf];
+    // ---- S^T tile: rows = 32 keys, cols = 32 queries ------------------------------------------------------------
+    floatx16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Kb[li * kFaLD + 2 * s + lh], qreg[s], st, 0, 0, 0);
+    // ---- online softmax over the 16 keys this lane holds (+ the other lane half) ---------------------------------
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int dist = qi > j ? qi - j : j - qi;
+      float x = st[r] - slope * (float)dist;
+      if (j >= T) x = -INFINITY;
+      st[r] = x;
+      mloc = fmaxf(mloc, x);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m, mloc);                  // finite from the first tile on (key 0 always exists)
+    const float alpha = __expf(m - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(st[r] - m_new);
+      st[r] = p;
+      lsum += p;
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    l = l * alpha + lsum;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    // ---- O^T += V^T P^T: k-step s contracts key j(s, lh); B operand = st[s] ---------------------------------------
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int jr = (s & 3) + 8 * (s >> 2) + 4 * lh;
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vb[jr * kFaLD + li], st[s], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vb[jr * kFaLD + 32 + li], st[s], o1, 0, 0, 0);
+    }
+    if (kt + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- normalise, transpose through LDS, coalesced row stores ------------------------------------------------------
+  const float inv = 1.f / l;
+  float* Os = &Ks[0][0];                                 // [64 queries][65]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    Os[(w * 32 + li) * kFaLD + d] = o0[r] * inv;
+    Os[(w * 32 + li) * kFaLD + 32 + d] = o1[r] * inv;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * (kFaHD / 4); e += 128) {
+    const int r = e / (kFaHD / 4), c4 = e % (kFaHD / 4);
+    if (q0 + r < T) {
+      const float* s_ = Os + r * kFaLD + c4 * 4;
+      *reinterpret_cast<float4*>(out + (size_t)(q0 + r) * ld + c4 * 4) = make_float4(s_[0], s_[1], s_[2], s_[3]);
+    }
+  }
+}
+
+}  // namespace
+
+// q, k, v, out: [B][Tp rows][ld floats], head h = columns [h*64, h*64 + 64); rows >= T are ignored (out rows >= T untouched)
+extern "C" int avdf_flash_attn_alibi(const float* q, const float* k, const float* v, float* out, const float* slopes, int B,
+                                     int T, int H, int hd, int ld, int64_t clip_stride, float scale, void* stream) {
+  AVDF_REQUIRE(q && k && v && out && B > 0 && T > 0 && H > 0, "flash_attn_alibi: bad args");
+  AVDF_REQUIRE(hd == kFaHD, "flash_attn_alibi: head dim %d not supported (64 only)", hd);
+  AVDF_REQUIRE(ld >= H * hd && ld % 4 == 0 && clip_stride % 4 == 0, "flash_attn_alibi: ld / clip stride must be multiples of 4 floats");
+  AVDF_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "flash_attn_alibi: 16-byte alignment");
+  AVDF_REQUIRE(H < 65536 && B < 65536, "flash_attn_alibi: grid limits");
+  hipLaunchKernelGGL(flash_attn_alibi_kernel, dim3((T + 63) / 64, H, B), dim3(128), 0, (hipStream_t)stream, q, k, v, out, slopes, T,
+                     ld, scale, (long)clip_stride);
+  AVDF_CHECK_LAUNCH("flash_attn_alibi");
+  return AVDF_OK;
+}

@@ -1,6 +1,7 @@
 """Frozen feature extractors of stage 1 (the reference's audio_feature/ and video_feature/ scripts)."""
 from .byola import AudioNTT2020Task6, LogMelFrontEnd, byola_features, byola_features_batch   # noqa: F401
-from .emotion2vec import Emotion2Vec, emotion2vec_features, emotion2vec_features_batch   # noqa: F401
+from .emotion2vec import (Emotion2Vec, emotion2vec_features, emotion2vec_features_batch,   # noqa: F401
+                          emotion2vec_features_equal_length)
 from .c3d import C3DVideoEncoder, get_video_encoder, video_features, chunk_plan   # noqa: F401
 
 
@@ -18,9 +19,11 @@ def extract_clip_batch(frames, pcm, c3d, byola, front_end, e2v, outs, audio_stre
     if audio_stream is not None:
         audio_stream.wait_stream(cur)
     with torch.cuda.stream(audio_stream if audio_stream is not None else cur):
+        # equal-length clips (a tensor [B, N]): one batched Emotion2Vec pass (row-wise GEMMs over B x T rows)
+        fes = emotion2vec_features_equal_length(pcm, e2v) if torch.is_tensor(pcm) and pcm.dim() == 2 else None
         for b in range(len(outs)):
             fa = byola_features(pcm[b], byola, front_end)
-            fe = emotion2vec_features(pcm[b], e2v)
+            fe = fes[b] if fes is not None else emotion2vec_features(pcm[b], e2v)
             outs[b][1].copy_(fa[:outs[b][1].shape[0]])
             outs[b][2].copy_(fe[:outs[b][2].shape[0]])
     for b in range(len(outs)):

@@ -8,8 +8,10 @@ conv_bias=False; named at audio.py:12-17).  Module / parameter names mirror the 
 EMA entries are pre-training only).  Every config field that changes the inference graph is a constructor argument
 because the real values live in the absent checkpoint's cfg.
 
-Inference only; one clip at a time (the reference pads a batch with zeros and passes padding_mask=None, so padded
-clips see their padding -- per-clip processing is the un-contaminated equivalent).  PARITY UNPINNED upstream: fairseq,
+Inference only.  `forward_clip` / `emotion2vec_features` process one clip (the un-contaminated equivalent of the
+reference, which pads a batch with zeros and passes padding_mask=None, so shorter clips attend to their padding);
+`forward_batch` runs equal-length clips in one pass and `emotion2vec_features_batch` reproduces the reference's
+zero-padded batch semantics on top of it.  PARITY UNPINNED upstream: fairseq,
 timm and the checkpoint are absent; tests pin the HIP path against a torch CPU restatement (oracle/emotion2vec_ref.py).
 """
 import math
@@ -124,20 +126,18 @@ class Emotion2Vec(nn.Module):
     def _linear(self, x, lin, act=ops.ACT_NONE):
         return ops.linear(x, lin.weight, lin.bias, act)
 
-    def _attention(self, x, attn, T, layer):
-        """AltAttention.forward (modules.py:280-322) for one clip; x [Tp, D] (rows >= T are padding).  All heads of a
-        layer run as ONE launch per step (batch-strided GEMMs: head h = column slice h*hd of q / k / out, its own
-        V^T rows as the weight matrix)."""
-        Tp, D = x.shape
+    def _attention(self, x, attn, B, T, Tp, layer):
+        """AltAttention.forward (modules.py:280-322) for B clips stacked as rows: x [B * Tp, D] (rows >= T of a clip are
+        padding).  q / k / v projections over all rows, then ONE fused launch for softmax(q k^T * scale + alibi) v over all
+        heads and clips (avdf_flash_attn_alibi: the [H, T, T] score matrices never reach HBM), then the projection."""
+        D = x.shape[1]
         H, hd = self.heads, D // self.heads
         st = torch.cuda.current_stream().cuda_stream
         w, b = attn.qkv.weight, attn.qkv.bias
         q = ops.linear(x, w[0:D], b[0:D])
         k = ops.linear(x, w[D:2 * D], b[D:2 * D])
         v = ops.linear(x, w[2 * D:3 * D], b[2 * D:3 * D])
-        vT = ops.transpose_last2(v.view(1, Tp, D))[0]                       # [D, Tp]
-        scores = torch.empty((H, Tp, Tp), dtype=torch.float32, device=x.device)
-        out = torch.zeros((Tp, D), dtype=torch.float32, device=x.device)
+        out = torch.zeros((B * Tp, D), dtype=torch.float32, device=x.device)
         enc = self.modality_encoders["AUDIO"]
         if enc.alibi_scale is not None:
             a = enc.alibi_scale.clamp_min(0)
@@ -145,19 +145,13 @@ class Emotion2Vec(nn.Module):
             slopes = (self._slopes * sc).contiguous()
         else:
             slopes = torch.zeros(H, dtype=torch.float32, device=x.device)
-        # S_h = Q_h K_h^T: batch = head, x = q + h*hd (row stride D), "weights" = k + h*hd, y = scores[h]
-        check(lib.avdf_conv1d_fwd_strided(q.data_ptr(), k.data_ptr(), None, scores.data_ptr(), H, T, hd, T, T, 1, 1, 0, D, D, Tp,
-                                          hd, hd, Tp * Tp, 0, st), "attn QK^T")
-        check(lib.avdf_softmax_alibi_heads(scores.data_ptr(), H, T, Tp, Tp * Tp, hd ** -0.5, slopes.data_ptr(), st),
-              "softmax_alibi_heads")
-        # O_h = P_h V_h: x = scores[h] (K = Tp), weights = V^T rows h*hd.. (row stride Tp), y = out + h*hd
-        check(lib.avdf_conv1d_fwd_strided(scores.data_ptr(), vT.data_ptr(), None, out.data_ptr(), H, T, Tp, T, hd, 1, 1, 0, Tp, Tp, D,
-                                          Tp * Tp, hd * Tp, hd, 0, st), "attn PV")
+        check(lib.avdf_flash_attn_alibi(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), slopes.data_ptr(), B, T, H, hd,
+                                        D, Tp * D, hd ** -0.5, st), "flash_attn_alibi")
         return self._linear(out, attn.proj)
 
-    def _block(self, x, blk, T, layer):
+    def _block(self, x, blk, B, T, Tp, layer):
         """post-LN AltBlock (modules.py:242-249): x += attn(x); r = x = norm1(x); x = norm2(r + mlp(x))."""
-        a = self._attention(x, blk.attn, T, layer)
+        a = self._attention(x, blk.attn, B, T, Tp, layer)
         x = ops.affine_residual(x.unsqueeze(0), None, a.unsqueeze(0), None, self._ones)[0]
         r = self._ln(x, blk.norm1)
         m = self._linear(self._linear(r, blk.mlp.fc1, ops.ACT_GELU), blk.mlp.fc2)
@@ -168,64 +162,77 @@ class Emotion2Vec(nn.Module):
     def forward_clip(self, pcm):
         """pcm [N] fp32 @16 kHz on the device -> [(N - 400) // 320 + 1, 768]."""
         assert not self.training and pcm.dim() == 1 and pcm.is_cuda
-        with ops.infer_mode():
-            return self._forward_clip(pcm)
+        return self.forward_batch(pcm.unsqueeze(0))[0]
 
-    def _forward_clip(self, pcm):
+    @torch.no_grad()
+    def forward_batch(self, pcm):
+        """pcm [B, N] (equal-length clips, e.g. the zero-padded batch of the reference's collate) -> [B, T, 768].  Every
+        row-wise operator (LayerNorm, the Linear layers: 8 of the 10 GEMMs of a block) runs ONCE over the B * T rows of
+        the batch instead of per clip (M = 1535 -> B x 1536 rows per launch); the temporal operators (feature convs,
+        positional convs, attention) keep the clips apart."""
+        assert not self.training and pcm.dim() == 2 and pcm.is_cuda
+        with ops.infer_mode():
+            return self._forward_batch(pcm.contiguous())
+
+    def _forward_batch(self, pcm):
         enc = self.modality_encoders["AUDIO"]
         st = torch.cuda.current_stream().cuda_stream
         dev = pcm.device
-        n = pcm.numel()
+        B, n = pcm.shape
         layers = enc.local_encoder.conv_layers
         # --- local_features (base.py:189-202): conv stack -> LN -> Linear ---------------------------------
         dim0, k0, s0 = CONV_SPEC[0]
         T = (n - k0) // s0 + 1
-        x = torch.empty((T, dim0), dtype=torch.float32, device=dev)
-        check(lib.avdf_wave_conv_c1(pcm.contiguous().data_ptr(), layers[0][0].weight.contiguous().data_ptr(),
-                                    x.data_ptr(), n, T, dim0, k0, s0, st), "wave_conv_c1")
-        x = self._ln(x, layers[0][2][1], 2)                                  # LayerNorm + GELU fused
+        x = torch.empty((B, T, dim0), dtype=torch.float32, device=dev)
+        w0 = layers[0][0].weight.contiguous()
+        for b in range(B):
+            check(lib.avdf_wave_conv_c1(pcm[b].data_ptr(), w0.data_ptr(), x[b].data_ptr(), n, T, dim0, k0, s0, st), "wave_conv_c1")
+        x = self._ln(x.view(B * T, dim0), layers[0][2][1], 2)                # LayerNorm + GELU fused
         for i in range(1, len(CONV_SPEC)):
             dim, k, s = CONV_SPEC[i]
             Tn = (T - k) // s + 1
-            y = torch.empty((Tn, dim), dtype=torch.float32, device=dev)
+            y = torch.empty((B * Tn, dim), dtype=torch.float32, device=dev)
             cin = x.shape[1]
             check(lib.avdf_conv1d_fwd_ex(x.data_ptr(), layers[i][0].weight.contiguous().data_ptr(), None, y.data_ptr(),
-                                         1, T, cin, Tn, dim, k, s, 0, cin, cin * k, dim, 0, st), "feature conv")
+                                         B, T, cin, Tn, dim, k, s, 0, cin, cin * k, dim, 0, st), "feature conv")
             x, T = self._ln(y, layers[i][2][1], 2), Tn
-        x = self._linear(self._ln(x, enc.project_features[1]), enc.project_features[2])
+        x = self._linear(self._ln(x, enc.project_features[1]), enc.project_features[2])            # [B * T, D]
         # --- contextualized_features (base.py:204-329), mask=False ---------------------------------------
         Tp = (T + 3) // 4 * 4               # row padding keeps every GEMM operand stride 16-byte aligned
         D = self.embed_dim
-        xp = torch.zeros((Tp, D), dtype=torch.float32, device=dev)
-        xp[:T] = x
+        xp = torch.zeros((B, Tp, D), dtype=torch.float32, device=dev)
+        xp[:, :T] = x.view(B, T, D)
         h = xp
         for i in range(1, len(enc.relative_positional_encoder) - 1):
             conv = enc.relative_positional_encoder[i][0]
-            y = torch.zeros((Tp, D), dtype=torch.float32, device=dev)
+            y = torch.zeros((B, Tp, D), dtype=torch.float32, device=dev)
             kpos = conv.weight.shape[2]
             # k=19 / 16 groups (every released checkpoint): each group is a 48-channel GEMM slice on the MFMA kernel
             # (2.15 GF per layer: 290 -> ~50 us); other kernel sizes keep the scalar kernel
             fn = lib.avdf_grouped_conv1d_fwd if (kpos == 19 and (D // self.conv_pos_groups) % 4 == 0) else lib.avdf_grouped_conv_pos
-            check(fn(h.data_ptr(), conv.weight.contiguous().data_ptr(), conv.bias.data_ptr(), y.data_ptr(), T, D,
-                     self.conv_pos_groups, kpos, st), "grouped_conv_pos")
-            h = torch.zeros_like(y)
-            h[:T] = ops.layernorm(y[:T], None, None, 1e-5, 2)                # LN (no affine) + GELU
-        x = ops.affine_residual(xp.unsqueeze(0), None, h.unsqueeze(0), None, self._ones)[0]
+            wc, bc = conv.weight.contiguous(), conv.bias
+            for b in range(B):
+                check(fn(h[b].data_ptr(), wc.data_ptr(), bc.data_ptr(), y[b].data_ptr(), T, D, self.conv_pos_groups, kpos, st),
+                      "grouped_conv_pos")
+            h = ops.layernorm(y.view(B * Tp, D), None, None, 1e-5, 2).view(B, Tp, D)        # LN (no affine) + GELU
+            if Tp > T:
+                h[:, T:].zero_()                                             # the next conv's zero padding past the clip end
+        x = ops.affine_residual(xp.view(1, B * Tp, D), None, h.view(1, B * Tp, D), None, self._ones)[0]
         x = self._ln(x, enc.context_encoder.norm)                            # BlockEncoder: norm first (modules.py:73-74)
         layer = 0
         for blk in enc.context_encoder.blocks:
-            x = self._block(x, blk, T, layer)
+            x = self._block(x, blk, B, T, Tp, layer)
             layer += 1
         for blk in self.blocks:
-            x = self._block(x, blk, T, layer)
+            x = self._block(x, blk, B, T, Tp, layer)
             layer += 1
-        return x[:T]
+        return x.view(B, Tp, D)[:, :T]
 
     @torch.no_grad()
     def extract_features(self, source, padding_mask=None, mask=False):
         """Reference entry point (emotion2vec.py:177-188): source [B, N] -> {'x': [B, T, 768]}."""
         assert padding_mask is None and not mask
-        return {"x": torch.stack([self.forward_clip(source[b]) for b in range(source.shape[0])]),
+        return {"x": self.forward_batch(source),
                 "padding_mask": None, "layer_results": [], "mask": None}
 
 
@@ -242,10 +249,20 @@ def emotion2vec_features(pcm, model, n_samples=None, pad_samples=None):
 
 
 @torch.no_grad()
+def emotion2vec_features_equal_length(pcm, model):
+    """pcm [B, N] of equal-length clips -> list of per-clip feature arrays, one batched encoder pass."""
+    x = model.forward_batch(pcm)
+    k = int(50 * (pcm.shape[1] / 16000.0) - 0.817)
+    return [x[b, :k] for b in range(pcm.shape[0])]
+
+
+@torch.no_grad()
 def emotion2vec_features_batch(pcms, model):
     """The reference's batch semantics (scripts/extract_audio_feature_batch.py:35-52,73-91): waveforms zero-padded to the
     longest of the batch, `extract_features(wav, padding_mask=None)` -- so the attention of a shorter clip also attends to
     its padding positions -- then rows [: int(50 * len - 0.817)] per clip.  No operator of the encoder mixes clips, so
     clip i of the padded batch is the per-clip forward of its zero-padded waveform."""
     longest = max(int(p.numel()) for p in pcms)
-    return [emotion2vec_features(p, model, pad_samples=longest) for p in pcms]
+    batch = torch.stack([torch.nn.functional.pad(p, (0, longest - p.numel())) for p in pcms])
+    x = model.forward_batch(batch)
+    return [x[i, :int(50 * (p.numel() / 16000.0) - 0.817)] for i, p in enumerate(pcms)]

@@ -314,6 +314,13 @@ int avdf_softmax_alibi(float* scores, int T, int ld, float qk_scale, float slope
 int avdf_softmax_alibi_heads(float* scores, int H, int T, int ld, int64_t head_stride, float qk_scale,
                              const float* slopes, void* stream);
 
+/* Fused attention of one Emotion2Vec layer (AltAttention.forward, upstream/models/modules.py:280-322; ALiBi of
+ * base.py:538-604): out = softmax(q k^T * scale - slopes[h] * |i - j|) v for all H heads in one launch; the
+ * [H, T, T] scores stay on chip (exact-fp32 MFMA, online softmax).  q / k / v / out: [B][rows][ld] fp32, head h =
+ * columns [h*hd, (h+1)*hd), hd = 64; rows >= T are ignored (out rows >= T are not written).  slopes: device [H] or NULL. */
+int avdf_flash_attn_alibi(const float* q, const float* k, const float* v, float* out, const float* slopes, int B,
+                          int T, int H, int hd, int ld, int64_t clip_stride, float scale, void* stream);
+
 /* ---- fused AffineDropPath residual + LayerNorm (TransformerBlock: blocks.py:1311-1313, 870-872) ------------
  *   out = a*ma[b,t] + scale[c]*keep[b]*(r*mr[b,t]);  h = LN(out)*gamma + beta  (ma / mr / keep may be NULL)
  * backward: dout = gradient reaching `out` from its other consumer (NULL = none), dh = gradient of h.        */

@@ -346,7 +346,31 @@ def test_emotion2vec_attention_matches_reference_alt_attention(golden_dir):
             xp = torch.zeros((Np, dim), device="cuda:0")
             xp[:N] = x[b].to("cuda:0")
             with torch.no_grad():
-                out = md._attention(xp, md.blocks[0].attn, N, 1)[:N].cpu()
+                out = md._attention(xp, md.blocks[0].attn, 1, N, Np, 1)[:N].cpu()
             ref = torch.from_numpy(g[key][b])
             err = float((out - ref).abs().max() / ref.abs().max())
             assert err < 1e-4, (key, b, err)
+
+
+@pytest.mark.parametrize("T,H,with_alibi", [(57, 12, True), (1535, 12, True), (64, 3, False), (33, 2, True), (200, 1, True)])
+def test_flash_attention_matches_float64_softmax_attention(T, H, with_alibi):
+    """avdf_flash_attn_alibi (all heads of a layer, scores on chip) against softmax(q k^T / sqrt(64) - slope |i - j|) v in
+    float64, incl. a length that is not a multiple of the 32-key / 64-query tiles and padded rows that must stay untouched."""
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    hd, D = 64, 64 * H
+    Tp = (T + 3) // 4 * 4
+    g = torch.Generator().manual_seed(T * 7 + H)
+    q, k, v = (torch.randn(Tp, D, generator=g) for _ in range(3))
+    slopes = torch.rand(H, generator=g) * 0.5 if with_alibi else torch.zeros(H)
+    qd, kd, vd = (t[:T].double().view(T, H, hd).permute(1, 0, 2) for t in (q, k, v))
+    pos = -(torch.arange(T)[None, :] - torch.arange(T)[:, None]).abs().double()
+    s = qd @ kd.transpose(1, 2) * hd ** -0.5 + slopes.double()[:, None, None] * pos[None]
+    ref = (s.softmax(-1) @ vd).permute(1, 0, 2).reshape(T, D)
+    out = torch.full((Tp, D), 7.0, device="cuda:0")
+    qg, kg, vg, sg = q.cuda(), k.cuda(), v.cuda(), slopes.cuda()
+    check(lib.avdf_flash_attn_alibi(qg.data_ptr(), kg.data_ptr(), vg.data_ptr(), out.data_ptr(), sg.data_ptr() if with_alibi else None,
+                                    1, T, H, hd, D, Tp * D, hd ** -0.5, torch.cuda.current_stream().cuda_stream), "flash")
+    torch.cuda.synchronize()
+    err = float((out[:T].cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+    assert float((out[T:] - 7.0).abs().max()) == 0.0 if Tp > T else True

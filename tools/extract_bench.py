@@ -23,3 +23,5 @@ def t(fn, n=3):
 print(f"BYOL-A (log-mel + CNN + FC): {t(lambda: byola_features(pcm, byola, fe)):.2f} ms")
 print(f"Emotion2Vec:                 {t(lambda: emotion2vec_features(pcm, e2v)):.2f} ms")
 print(f"C3D:                         {t(lambda: video_features(frames, c3d)):.2f} ms")
+pcm8 = torch.rand(8, 491520, device=dev) - 0.5
+print(f"Emotion2Vec, 8 clips batched: {t(lambda: e2v.forward_batch(pcm8)) / 8:.2f} ms per clip")
