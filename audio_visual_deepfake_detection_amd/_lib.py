@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavdf_hip.so")
+LIB_PATH = os.environ.get("AVDF_LIB_PATH") or os.path.join(_HERE, "libavdf_hip.so")     # AVDF_LIB_PATH: A/B builds (tools)
 
 P, I, F, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
   float* __restrict__ ypre = pick3(ptrs.ypre, prob);
   // P = left zero-padding (K/2 for the "same" convs of the model, 0 for the wav2vec2 feature extractor);
   // ldx / ldw / ldy = row strides of x, w and y in floats (sub-matrix views: attention heads, weight slices)
-  static_assert(WM * WN == 4 || WM * WN == 1, "4 waves (or, for the 32x32 tile, 1 wave) per K-group");
+  static_assert(WM * WN == 4 || WM * WN == 2 || WM * WN == 1, "4 waves (64x32 tile: 2, 32x32 tile: 1) per K-group");
   static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
   constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -444,7 +444,7 @@ __device__ __forceinline__ void conv_dgrad_body(
   const float* __restrict__ mask = pick3(ptrs.mask, prob);
   const float* __restrict__ ypre = pick3(ptrs.ypre, prob);
   float* __restrict__ dx = pick3(ptrs.dx, prob);
-  static_assert(WM * WN == 4 || WM * WN == 1, "4 waves (or, for the 32x32 tile, 1 wave) per K-group");
+  static_assert(WM * WN == 4 || WM * WN == 2 || WM * WN == 1, "4 waves (64x32 tile: 2, 32x32 tile: 1) per K-group");
   static_assert(KC % (2 * KG) == 0, "K-tile must split evenly into k-pairs per group");
   constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
@@ -861,6 +861,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // >= 2 workgroups per CU wins, otherwise the shape with the most workgroups; then as many K-groups
 // as needed to put ~1024+ wave-quads on the chip.
 // tile 0: 128x128  1: 64x128  2: 64x64  3: 32x128  4: 256x64  5: 32x32 (K=1; table / tuner only)
+// tile 6: 64x32, two waves per K-group (table / tuner only): a [6144, 256] output is 768 such tiles = exactly 3 per CU,
+// all co-resident at 49.5 KB of LDS, where the 64x64 tile leaves half the CUs with one workgroup and half with two
 struct TilePlan { int tile, kg, db; };
 
 // ---- measured plans ----------------------------------------------------------------------------------------
@@ -870,7 +872,27 @@ struct TunedPlan { int kind, K, stride, M, N, Kred, a, b; };   // kind 0 fwd / 1
 static const TunedPlan kTuned[] = {
 #include "gemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
+// in-situ plan experiments without a rebuild (tools/plan_ab.py): AVDF_TUNED_EXTRA="kind,K,stride,M,N,Kred,a,b;..." rows are
+// looked up before the table (a = -1: pretend the table has no row for the shape -> heuristic plan)
+static TunedPlan g_extra[64];
+static const int g_nextra = [] {
+  const char* e = getenv("AVDF_TUNED_EXTRA");
+  int n = 0;
+  while (e && *e && n < 64) {
+    TunedPlan t;
+    int used = 0;
+    if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d%n", &t.kind, &t.K, &t.stride, &t.M, &t.N, &t.Kred, &t.a, &t.b, &used) != 8) break;
+    g_extra[n++] = t;
+    e += used;
+    if (*e == ';') ++e;
+  }
+  return n;
+}();
 inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, int Kred) {
+  for (int i = 0; i < g_nextra; ++i) {
+    const TunedPlan* t = &g_extra[i];
+    if (t->kind == kind && t->K == K && t->stride == stride && t->M == M && t->N == N && t->Kred == Kred) return t->a < 0 ? nullptr : t;
+  }
   for (const TunedPlan* t = kTuned; t->kind >= 0; ++t)
     if (t->kind == kind && t->K == K && t->stride == stride && t->M == M && t->N == N && t->Kred == Kred) return t;
   return nullptr;
@@ -886,10 +908,10 @@ static int g_override[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}
 inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, int stride = 0, int Kred = 0) {
   {
     const int kind = dgrad ? 1 : 0;
-    const int mk_[6] = {1, 2, 4, 4, 2, 4};
+    const int mk_[7] = {1, 2, 4, 4, 2, 4, 4};
     if (g_override[kind][0] >= 0) {
       TilePlan o{g_override[kind][0], g_override[kind][1] & 7, (g_override[kind][1] >> 3) & 1};
-      if (o.tile > 5) o.tile = 5;
+      if (o.tile > 6) o.tile = 6;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
       return o;
@@ -993,6 +1015,9 @@ int avdf_reduce_slabs(const float* ws, float* out, int nslab, int64_t n, int acc
 // convs W5_ = 2 aliases tile 2)
 #define AVDF_GEMM_DISPATCH(KS_, S_, KC0_, KC1_, KC2_, KC3_, KC4_, KC5_, W5_, L)    \
   switch (plan.tile * 8 + plan.kg) {                                               \
+    case 6 * 8 + 1: L(KS_, S_, KC2_, 2, 1, 1, 1, 1); break;                        \
+    case 6 * 8 + 2: L(KS_, S_, KC2_, 2, 1, 1, 1, 2); break;                        \
+    case 6 * 8 + 4: L(KS_, S_, KC2_, 2, 1, 1, 1, 4); break;                        \
     case 5 * 8 + 1: L(KS_, S_, KC5_, W5_, W5_, 1, 1, (W5_ == 1 ? 4 : 1)); break;   \
     case 5 * 8 + 2: L(KS_, S_, KC5_, W5_, W5_, 1, 1, (W5_ == 1 ? 8 : 2)); break;   \
     case 5 * 8 + 4: L(KS_, S_, KC5_, W5_, W5_, 1, 1, (W5_ == 1 ? 16 : 4)); break;  \
@@ -1384,11 +1409,12 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
       const TunedPlan* t = tuned_lookup(4, 1, 1, n * T, Cin, Cout);
       if (t) { a = t->a; b = t->b; }
     }
-    if (a >= 0 && a <= 5 && (b >> 3) >= 1) {
-      const int mk_[6] = {1, 2, 4, 4, 2, 4};
+    if (a >= 0 && a <= 6 && (b >> 3) >= 1) {
+      const int mk_[7] = {1, 2, 4, 4, 2, 4, 4};
       int kg = b & 7;
       if (kg != 1 && kg != 2 && kg != 4) kg = 1;
       if (kg > mk_[a]) kg = mk_[a];
+      if (a == 6 && kg == 1) kg = 2;                 // the wgrad half needs 4 waves per K-group: >= 256 threads
       plan = TilePlan{a, kg, 0};
       const int total = B * p.tilesPerClip;
       int want = b >> 3;
@@ -1397,6 +1423,7 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
       p.splits = cdiv(total, p.tilesPerSplit);
     }
   }
+  if (plan.tile == 6 && plan.kg == 1) plan.kg = 2;   // 64x32 tile: two waves per K-group, the wgrad half needs four per workgroup
   if (!g_pair_mode || !p.small) {
     int rc = conv1d_dgrad_launch(d, n, B, T, Cin, T, Cout, 1, 1, act, st);
     if (rc) return rc;
@@ -1409,9 +1436,13 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
     const int dgx = B * tilesT, dgy = cdiv(Cin, BN_);                                                               \
     const int wgx = p.mtiles * n, wgy = p.ctiles, wgz = p.splits;                                                   \
     const int nW = wgx * wgy * wgz, nD = dgx * dgy * n;                                                             \
-    hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_>), dim3(nW + nD), dim3(64 * WM_ * WN_ * KG_), 0,  \
-                       st, d, g, nW, wgx, wgy, wgz, dgx, dgy, p.mtiles, B, T, Cin, Cout, act, tilesT,               \
-                       p.tilesPerClip, p.tilesPerSplit);                                                            \
+    if constexpr ((WM_ * WN_ * KG_) % 4 == 0) {                                                                     \
+      hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_>), dim3(nW + nD), dim3(64 * WM_ * WN_ * KG_), 0,  \
+                         st, d, g, nW, wgx, wgy, wgz, dgx, dgy, p.mtiles, B, T, Cin, Cout, act, tilesT,             \
+                         p.tilesPerClip, p.tilesPerSplit);                                                          \
+    } else {                                                                                                        \
+      AVDF_REQUIRE(false, "conv1d_bwd_pair: plan with fewer than 4 waves per workgroup");                           \
+    }                                                                                                               \
   } while (0)
   AVDF_GEMM_DISPATCH(1, 1, 64, 64, 128, 64, 32, 128, 1, LAUNCH_PAIR)
 #undef LAUNCH_PAIR

@@ -331,6 +331,8 @@ class TrainStep:
                 self._outs = None
             self.flat_g.zero_()
         torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            torch.distributed.barrier(group=self.pg)       # no collective of the set-up phase is in flight during capture
         self.model._loss_norm_state.copy_(norm_state)
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, self.dev)
@@ -338,7 +340,8 @@ class TrainStep:
 
         def grab(fns):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=s):
+            # thread_local: the RCCL watchdog thread of torch.distributed may query events while this thread captures
+            with torch.cuda.graph(g, pool=pool, stream=s, capture_error_mode="thread_local"):
                 for fn in fns:
                     fn()
             return g

@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the eager per-launch timing pass (tools/plan_ab.py)")
     ap.add_argument("--wgrad-side", action="store_true",
                     help="weight-gradient GEMMs on a second HIP stream (measured slower inside hipGraphs: 558 vs 611 clips/s)")
     ap.add_argument("--branch-streams", action="store_true", help="run the q/k/v chains on three HIP streams")
@@ -331,6 +332,12 @@ def main():
     # A GPU-side spin is queued first so that the host has enqueued the whole step before the first kernel runs:
     # the events then bracket back-to-back GPU execution (no host launch gaps inside the brackets).
     roof = None
+    if args.no_roofline:
+        if rank == 0:
+            print(json.dumps({"value": round(clips_per_s, 2), "ms_per_step": round(dt / args.steps * 1e3, 3)}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     bf3 = (args.mode != "train" and args.bf16x3)
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if bf3 else PEAK_F32_MFMA_TFLOPS
     if args.mode == "train":

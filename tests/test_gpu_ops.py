@@ -519,9 +519,9 @@ def test_conv1d_every_gemm_plan(ops, shape):
     xd, wd, dyd = g32(x), g32(w), g32(dy)
     st = torch.cuda.current_stream().cuda_stream
     try:
-        for tile in range(6):
+        for tile in range(7):
             for kg in (1, 2, 4):
-                if kg > (1, 2, 4, 4, 2, 4)[tile]:
+                if kg > (1, 2, 4, 4, 2, 4, 4)[tile]:
                     continue
                 for db in (0, 1):
                     check(lib.avdf_gemm_override(0, tile, kg + 8 * db), "override")
@@ -570,9 +570,9 @@ def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
     dx_sep = [torch.empty(B, T, Cin, device=dev()) for _ in range(n)]
     try:
         check(lib.avdf_gemm_override(4, -2, -2), "override")      # the pair's own table rows off: plans come from kind 1 / 2
-        for tile in range(6):
+        for tile in range(7):
             for kg in (1, 2, 4):
-                if kg > (1, 2, 4, 4, 2, 4)[tile]:
+                if kg > (1, 2, 4, 4, 2, 4, 4)[tile] or (tile == 6 and kg == 1):     # 64x32 tile: the fused launch needs kg >= 2
                     continue
                 check(lib.avdf_gemm_override(1, tile, kg), "override")
                 check(lib.avdf_conv1d_bwd_data_grouped(n, tab(dys), tab(ws_), tab(masks), tab(ypres), tab(dx_sep), B, T, Cin, T, Cout,

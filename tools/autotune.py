@@ -49,7 +49,7 @@ def bench_shape(shape, iters):
     ys = [torch.randn(B, Tout, Cout, device=dev) for _ in range(n)]
     dws = [torch.zeros_like(w) for w in ws_]
     T = lambda ts: ops._ptr_table(ts)
-    tiles = [(t, kg) for t in range(6) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2, 4)[t]]
+    tiles = [(t, kg) for t in range(7) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2, 4, 4)[t]]
     if kind == "pair":
         # (dgrad tile, K-groups) x (wgrad token splits); the baseline is the table / heuristic plan of the two halves
         dxs = [torch.empty_like(x) for x in xs]
@@ -117,7 +117,7 @@ def bench_ex(shape, iters):
     assert Tout == (Tin + 2 * pad - K) // s + 1, shape
     fn = lambda: check(lib.avdf_conv1d_fwd_strided(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, Tin, Cin, Tout, Cout, K, s, pad,
                                                    Cin, Cin * K, Cout, Tin * Cin, 0, Tout * Cout, 0, st()), "ex")
-    tiles = [(t, kg) for t in range(6) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2, 4)[t]]
+    tiles = [(t, kg) for t in range(7) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2, 4, 4)[t]]
     if K != 1:
         tiles = [tk for tk in tiles if tk[0] != 5]
     check(lib.avdf_gemm_override(0, -2, -2), "o")

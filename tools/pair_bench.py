@@ -32,9 +32,9 @@ def main():
         check(lib.avdf_bwd_pair_mode(1), "m")
         t_pair = timeit(run)
         best = (t_pair, None)
-        for tile in range(6):
+        for tile in range(7):
             for kg in (1, 2, 4):
-                if kg > (1, 2, 4, 4, 2, 4)[tile]:
+                if kg > (1, 2, 4, 4, 2, 4, 4)[tile]:
                     continue
                 for splits in (1, 2, 4, 8, 16, 32, 64):
                     if splits > B * ((T + 127) // 128):
