@@ -40,6 +40,8 @@ SIGNATURES = {
     "avdf_local_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "avdf_local_attn_bwd_ws": (L, [I, I, I, I]),
     "avdf_local_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_local_attn_fwd_ex": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_local_attn_bwd_ex": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "avdf_global_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "avdf_global_attn_bwd_ws": (L, [I, I, I, I]),
     "avdf_global_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),

@@ -13,7 +13,7 @@ template <int W>
 __global__ __launch_bounds__(256) void local_attn_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kvmask, float* __restrict__ out, float* __restrict__ probs,
-    int B, int T, int H, int hs, float scale) {
+    int B, int T, int H, int hs, float scale, const float* __restrict__ rel, const float* __restrict__ tw) {
   constexpr int w = W / 2;
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void local_attn_fwd_kernel(
     if (tk >= 0 && tk < T) {
       const float kd = on ? k[(b * T + tk) * C + h * hs + lane] : 0.f;
       float d = wave_sum(qd * kd);
+      if (rel) d += rel[h * W + j];                      // relative position bias (blocks.py:1188-1189)
       d += (kvmask[b * T + tk] == 0.f) ? -1e4f : 0.f;
       s[j] = d;
     } else {
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void local_attn_fwd_kernel(
     const int tk = t + j - w;
     const float p = s[j] * inv;
     if (probs && lane == 0) probs[(bt * H + h) * W + j] = p;
-    if (tk >= 0 && tk < T && on) o += p * v[(b * T + tk) * C + h * hs + lane];
+    const float pe = tw ? p * tw[h * W + j] : p;          // time weighting after the softmax (blocks.py:1211-1212)
+    if (tk >= 0 && tk < T && on) o += pe * v[(b * T + tk) * C + h * hs + lane];
   }
   if (on) out[bt * C + h * hs + lane] = o;
 }
@@ -62,7 +64,7 @@ template <int W>
 __global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(
     const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ probs, float* __restrict__ dq, float* __restrict__ dS,
-    int B, int T, int H, int hs, float scale) {
+    int B, int T, int H, int hs, float scale, const float* __restrict__ tw, float* __restrict__ dT) {
   constexpr int w = W / 2;
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(
     } else {
       dp[j] = 0.f;
     }
+    if (dT && lane == 0) dT[(bt * H + h) * W + j] = p[j] * dp[j];     // d time_weighting[h, j] summand
+    if (tw) dp[j] *= tw[h * W + j];
     dot += p[j] * dp[j];
   }
   float acc = 0.f;
@@ -104,7 +108,7 @@ template <int W>
 __global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(
     const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ probs,
     const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv,
-    int B, int T, int H, int hs, float scale) {
+    int B, int T, int H, int hs, float scale, const float* __restrict__ tw) {
   constexpr int w = W / 2;
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(
     if (t >= 0 && t < T) {
       const long bt = b * T + t;
       const float ds = dS[(bt * H + h) * W + j];
-      const float p = probs[(bt * H + h) * W + j];
+      const float p = probs[(bt * H + h) * W + j] * (tw ? tw[h * W + j] : 1.f);
       ak += ds * q[bt * C + h * hs + lane];
       av += p * dout[bt * C + h * hs + lane];
     }
@@ -151,7 +155,7 @@ template <int W, int L>
 __global__ __launch_bounds__(256) void local_attn_fwd_rows_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ kvmask, float* __restrict__ out, float* __restrict__ probs,
-    int B, int T, int H, int hs, float scale, int runs) {
+    int B, int T, int H, int hs, float scale, int runs, const float* __restrict__ rel, const float* __restrict__ tw) {
   constexpr int w = W / 2, NR = kAttnTok + 2 * w;
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -161,6 +165,9 @@ __global__ __launch_bounds__(256) void local_attn_fwd_rows_kernel(
   const int C = H * hs, c = lane * 4;
   const bool on = c < C;
   const int h = on ? c / hs : 0;
+  float relb[W], twb[W];                      // per-head bias before / weight after the softmax (blocks.py:1188-1212)
+#pragma unroll
+  for (int j = 0; j < W; ++j) { relb[j] = rel ? rel[h * W + j] : 0.f; twb[j] = tw ? tw[h * W + j] : 1.f; }
   float4 kr[NR], vr[NR];
   float pen[NR];
 #pragma unroll
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256) void local_attn_fwd_rows_kernel(
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      s[j] = group_sum<L>(dot4(q4, kr[i + j])) + pen[i + j];        // -inf outside [0,T)
+      s[j] = group_sum<L>(dot4(q4, kr[i + j])) + relb[j] + pen[i + j];        // -inf outside [0,T)
       m = fmaxf(m, s[j]);
     }
     float den = 0.f;
@@ -193,8 +200,9 @@ __global__ __launch_bounds__(256) void local_attn_fwd_rows_kernel(
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      const float p = s[j] * inv;
+      float p = s[j] * inv;
       if (probs && on && (lane & (L - 1)) == 0) probs[(bt * H + h) * W + j] = p;
+      p *= twb[j];
       o.x += p * vr[i + j].x; o.y += p * vr[i + j].y; o.z += p * vr[i + j].z; o.w += p * vr[i + j].w;
     }
     if (on) *reinterpret_cast<float4*>(out + bt * C + c) = o;
@@ -206,7 +214,7 @@ template <int W, int L>
 __global__ __launch_bounds__(256) void local_attn_bwd_q_rows_kernel(
     const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ probs, float* __restrict__ dq, float* __restrict__ dS,
-    int B, int T, int H, int hs, float scale, int runs) {
+    int B, int T, int H, int hs, float scale, int runs, const float* __restrict__ tw, float* __restrict__ dT) {
   constexpr int w = W / 2, NR = kAttnTok + 2 * w;
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -216,6 +224,9 @@ __global__ __launch_bounds__(256) void local_attn_bwd_q_rows_kernel(
   const int C = H * hs, c = lane * 4;
   const bool on = c < C;
   const int h = on ? c / hs : 0;
+  float twb[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) twb[j] = tw ? tw[h * W + j] : 1.f;
   float4 kr[NR], vr[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -235,6 +246,8 @@ __global__ __launch_bounds__(256) void local_attn_bwd_q_rows_kernel(
     for (int j = 0; j < W; ++j) {
       p[j] = on ? probs[(bt * H + h) * W + j] : 0.f;
       dp[j] = group_sum<L>(dot4(go, vr[i + j]));      // rows outside [0,T) are zero -> dp = 0, and p = 0 there
+      if (dT && on && (lane & (L - 1)) == 0) dT[(bt * H + h) * W + j] = p[j] * dp[j];
+      dp[j] *= twb[j];
       dot += p[j] * dp[j];
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,7 +266,7 @@ template <int W>
 __global__ __launch_bounds__(256) void local_attn_bwd_kv_rows_kernel(
     const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ probs,
     const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv,
-    int B, int T, int H, int hs, float scale, int runs) {
+    int B, int T, int H, int hs, float scale, int runs, const float* __restrict__ tw) {
   constexpr int w = W / 2, NR = kAttnTok + 2 * w;
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -263,6 +276,9 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kv_rows_kernel(
   const int C = H * hs, c = lane * 4;
   if (c >= C) return;
   const int h = c / hs;
+  float twb[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) twb[j] = tw ? tw[h * W + j] : 1.f;
   float4 qr[NR], gr[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(256) void local_attn_bwd_kv_rows_kernel(
         const int r = i + 2 * w - j;
         const long bt = b * T + t;
         const float ds = dS[(bt * H + h) * W + j];
-        const float p = probs[(bt * H + h) * W + j];
+        const float p = probs[(bt * H + h) * W + j] * twb[j];
         ak.x += ds * qr[r].x; ak.y += ds * qr[r].y; ak.z += ds * qr[r].z; ak.w += ds * qr[r].w;
         av.x += p * gr[r].x; av.y += p * gr[r].y; av.z += p * gr[r].z; av.w += p * gr[r].w;
       }
@@ -451,16 +467,27 @@ __global__ __launch_bounds__(256) void global_attn_bwd_kv_kernel(
     default: avdf_set_error("local_attn: window %d unsupported (odd 3..19)", W_); return AVDF_EINVAL; \
   }
 
+extern "C" int avdf_local_attn_fwd_ex(const float* q, const float* k, const float* v, const float* kvmask, const float* rel,
+                                      const float* tw, float* out, float* probs, int B, int T, int H, int hs, int window,
+                                      float scale, void* stream);
 extern "C" int avdf_local_attn_fwd(const float* q, const float* k, const float* v, const float* kvmask,
                                    float* out, float* probs, int B, int T, int H, int hs, int window,
                                    float scale, void* stream) {
+  return avdf_local_attn_fwd_ex(q, k, v, kvmask, nullptr, nullptr, out, probs, B, T, H, hs, window, scale, stream);
+}
+
+// rel / tw: optional [H, window] tables -- relative position bias added to the scores before the softmax and time
+// weighting applied to the probabilities after it (LocalMaskedMHCA use_rel_pe / use_time_weight, blocks.py:1188-1212)
+extern "C" int avdf_local_attn_fwd_ex(const float* q, const float* k, const float* v, const float* kvmask, const float* rel,
+                                      const float* tw, float* out, float* probs, int B, int T, int H, int hs, int window,
+                                      float scale, void* stream) {
   AVDF_REQUIRE(q && k && v && kvmask && out, "local_attn_fwd: null pointer");
   AVDF_REQUIRE(B > 0 && T > 0 && H > 0 && hs > 0 && hs <= 64, "local_attn_fwd: bad dims (hs=%d must be <= 64)", hs);
   hipStream_t st = (hipStream_t)stream;
   if (rows_path_ok(H, hs) && ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0)) {
     const int runs = cdiv(T, kAttnTok);
     const dim3 grid((unsigned)(((long)B * runs + 3) / 4));
-#define CALL_L(WW, LL) hipLaunchKernelGGL((local_attn_fwd_rows_kernel<WW, LL>), grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale, runs)
+#define CALL_L(WW, LL) hipLaunchKernelGGL((local_attn_fwd_rows_kernel<WW, LL>), grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale, runs, rel, tw)
 #define CALL(WW) DISPATCH_L(hs / 4, WW, CALL_L)
     DISPATCH_W(window, CALL)
 #undef CALL
@@ -470,7 +497,7 @@ extern "C" int avdf_local_attn_fwd(const float* q, const float* k, const float* 
   }
   const long waves = (long)B * T * H;
   const dim3 grid((unsigned)((waves + 3) / 4));
-#define CALL(WW) hipLaunchKernelGGL(local_attn_fwd_kernel<WW>, grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale)
+#define CALL(WW) hipLaunchKernelGGL(local_attn_fwd_kernel<WW>, grid, dim3(256), 0, st, q, k, v, kvmask, out, probs, B, T, H, hs, scale, rel, tw)
   DISPATCH_W(window, CALL)
 #undef CALL
   AVDF_CHECK_LAUNCH("local_attn_fwd");
@@ -479,9 +506,20 @@ extern "C" int avdf_local_attn_fwd(const float* q, const float* k, const float* 
 
 extern "C" int64_t avdf_local_attn_bwd_ws(int B, int T, int H, int window) { return (int64_t)B * T * H * window; }
 
+extern "C" int avdf_local_attn_bwd_ex(const float* dout, const float* q, const float* k, const float* v, const float* probs,
+                                      const float* tw, float* dq, float* dk, float* dv, float* ws, float* dT, int B, int T,
+                                      int H, int hs, int window, float scale, void* stream);
 extern "C" int avdf_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
                                    const float* probs, float* dq, float* dk, float* dv, float* ws,
                                    int B, int T, int H, int hs, int window, float scale, void* stream) {
+  return avdf_local_attn_bwd_ex(dout, q, k, v, probs, nullptr, dq, dk, dv, ws, nullptr, B, T, H, hs, window, scale, stream);
+}
+
+// ws receives dS [B, T, H, window] (its column sums over (b, t) are the gradient of `rel`); dT (optional, same shape)
+// receives p * (dout . v): its column sums are the gradient of `tw`
+extern "C" int avdf_local_attn_bwd_ex(const float* dout, const float* q, const float* k, const float* v, const float* probs,
+                                      const float* tw, float* dq, float* dk, float* dv, float* ws, float* dT, int B, int T,
+                                      int H, int hs, int window, float scale, void* stream) {
   AVDF_REQUIRE(dout && q && k && v && probs && dq && dk && dv && ws, "local_attn_bwd: null pointer");
   AVDF_REQUIRE(B > 0 && T > 0 && H > 0 && hs > 0 && hs <= 64, "local_attn_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
@@ -489,10 +527,10 @@ extern "C" int avdf_local_attn_bwd(const float* dout, const float* q, const floa
       ((((uintptr_t)dout | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0)) {
     const int runs = cdiv(T, kAttnTok);
     const dim3 grid((unsigned)(((long)B * runs + 3) / 4));
-#define CALL_L(WW, LL) hipLaunchKernelGGL((local_attn_bwd_q_rows_kernel<WW, LL>), grid, dim3(256), 0, st, dout, k, v, probs, dq, ws, B, T, H, hs, scale, runs)
+#define CALL_L(WW, LL) hipLaunchKernelGGL((local_attn_bwd_q_rows_kernel<WW, LL>), grid, dim3(256), 0, st, dout, k, v, probs, dq, ws, B, T, H, hs, scale, runs, tw, dT)
 #define CALL(WW)                       \
   DISPATCH_L(hs / 4, WW, CALL_L);      \
-  hipLaunchKernelGGL(local_attn_bwd_kv_rows_kernel<WW>, grid, dim3(256), 0, st, dout, q, probs, ws, dk, dv, B, T, H, hs, scale, runs)
+  hipLaunchKernelGGL(local_attn_bwd_kv_rows_kernel<WW>, grid, dim3(256), 0, st, dout, q, probs, ws, dk, dv, B, T, H, hs, scale, runs, tw)
     DISPATCH_W(window, CALL)
 #undef CALL
 #undef CALL_L
@@ -502,8 +540,8 @@ extern "C" int avdf_local_attn_bwd(const float* dout, const float* q, const floa
   const long waves = (long)B * T * H;
   const dim3 grid((unsigned)((waves + 3) / 4));
 #define CALL(WW)                                                                                             \
-  hipLaunchKernelGGL(local_attn_bwd_q_kernel<WW>, grid, dim3(256), 0, st, dout, k, v, probs, dq, ws, B, T, H, hs, scale); \
-  hipLaunchKernelGGL(local_attn_bwd_kv_kernel<WW>, grid, dim3(256), 0, st, dout, q, probs, ws, dk, dv, B, T, H, hs, scale)
+  hipLaunchKernelGGL(local_attn_bwd_q_kernel<WW>, grid, dim3(256), 0, st, dout, k, v, probs, dq, ws, B, T, H, hs, scale, tw, dT); \
+  hipLaunchKernelGGL(local_attn_bwd_kv_kernel<WW>, grid, dim3(256), 0, st, dout, q, probs, ws, dk, dv, B, T, H, hs, scale, tw)
   DISPATCH_W(window, CALL)
 #undef CALL
   AVDF_CHECK_LAUNCH("local_attn_bwd");

@@ -175,7 +175,6 @@ class _MHCABase(nn.Module):
                  proj_pdrop=0.0, use_rel_pe=False, use_time_weight=False):
         super().__init__()
         assert n_embd % n_head == 0
-        assert not use_rel_pe and not use_time_weight, "rel_pe / time_weight are off in every shipped config"
         assert attn_pdrop == 0.0 and proj_pdrop == 0.0, "dropout inside attention is 0 in every shipped config"
         assert (n_qx_stride == 1) or (n_qx_stride % 2 == 0)
         assert (n_kv_stride == 1) or (n_kv_stride % 2 == 0)
@@ -198,6 +197,15 @@ class _MHCABase(nn.Module):
         self.query = nn.Conv1d(n_embd, n_embd, 1)
         self.value = nn.Conv1d(n_embd, n_embd, 1)
         self.proj = nn.Conv1d(n_embd, n_embd, 1)
+        # local attention only (blocks.py:968-975): per-head relative position bias before the softmax, per-head time
+        # weighting after it; the parameter names end in `rel_pe` / `time_weighting` for make_optimizer's no-decay rule
+        self.use_rel_pe = bool(use_rel_pe) and window_size > 1
+        self.use_time_weight = bool(use_time_weight) and window_size > 1
+        if self.use_rel_pe:
+            self.rel_pe = nn.Parameter(torch.zeros(1, 1, n_head, window_size))
+            nn.init.trunc_normal_(self.rel_pe, std=(2.0 / n_embd) ** 0.5)
+        if self.use_time_weight:
+            self.time_weighting = nn.Parameter(torch.ones(1, n_head, window_size))
 
     def _branch(self, conv, norm, proj, x, mask):
         y, out_mask = conv(x, mask)
@@ -229,7 +237,9 @@ class _MHCABase(nn.Module):
 
     def _core(self, q, k, v, qx_mask, kv_mask):
         if self.window_size > 1:
-            out = ops.local_attention(q, k, v, kv_mask, self.n_head, self.window_size)
+            out = ops.local_attention(q, k, v, kv_mask, self.n_head, self.window_size,
+                                      self.rel_pe if self.use_rel_pe else None,
+                                      self.time_weighting if self.use_time_weight else None)
         else:
             out = ops.global_attention(q, k, v, kv_mask, self.n_head)
         out = ops.conv1d(out, self.proj.weight, self.proj.bias, qx_mask)

@@ -731,8 +731,11 @@ def dwconv(x, w, mask=None, stride=1):
 # attention cores
 # --------------------------------------------------------------------------------------------
 class LocalAttnFn(torch.autograd.Function):
+    """Banded attention core; rel_pe [1,1,H,W] / time_w [1,H,W] are the optional per-head tables of use_rel_pe /
+    use_time_weight (blocks.py:968-975): a bias on the scores before the softmax, a weight on the probabilities after it."""
+
     @staticmethod
-    def forward(ctx, q, k, v, kvmask, n_head, window):
+    def forward(ctx, q, k, v, kvmask, n_head, window, rel_pe=None, time_w=None):
         q, k, v, kvmask = _c(q), _c(k), _c(v), _c(kvmask)
         B, T, C = q.shape
         assert k.shape == q.shape and v.shape == q.shape, "local attention needs equal q/k/v lengths"
@@ -742,22 +745,41 @@ class LocalAttnFn(torch.autograd.Function):
         out = torch.empty_like(q)
         need = any(ctx.needs_input_grad)
         probs = torch.empty((B, T, n_head, window), dtype=q.dtype, device=q.device) if need else None
-        check(lib.avdf_local_attn_fwd(_p(q), _p(k), _p(v), _p(kvmask), _p(out), _p(probs), B, T, n_head, hs, window,
-                                      scale, _stream()), "local_attn_fwd")
-        ctx.save_for_backward(q, k, v, probs)
+        rel = None if rel_pe is None else rel_pe.contiguous().view(-1)
+        tw = None if time_w is None else time_w.contiguous().view(-1)
+        assert (rel is None or rel.numel() == n_head * window) and (tw is None or tw.numel() == n_head * window)
+        check(lib.avdf_local_attn_fwd_ex(_p(q), _p(k), _p(v), _p(kvmask), _p(rel), _p(tw), _p(out), _p(probs), B, T, n_head, hs,
+                                         window, scale, _stream()), "local_attn_fwd")
+        ctx.save_for_backward(q, k, v, probs, tw)
         ctx.cfg = (B, T, n_head, hs, window, scale)
+        ctx.main = (_main_grad(rel_pe), _main_grad(time_w))
+        ctx.shapes = (None if rel_pe is None else rel_pe.shape, None if time_w is None else time_w.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, probs = ctx.saved_tensors
+        q, k, v, probs, tw = ctx.saved_tensors
         B, T, H, hs, window, scale = ctx.cfg
         dout = dout.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = _ws(lib.avdf_local_attn_bwd_ws(B, T, H, window), q)
-        check(lib.avdf_local_attn_bwd(_p(dout), _p(q), _p(k), _p(v), _p(probs), _p(dq), _p(dk), _p(dv), _p(ws),
-                                      B, T, H, hs, window, scale, _stream()), "local_attn_bwd")
-        return dq, dk, dv, None, None, None
+        need_rel, need_tw = ctx.shapes[0] is not None, ctx.shapes[1] is not None
+        dT = torch.empty(B * T * H * window, dtype=torch.float32, device=q.device) if need_tw else None
+        check(lib.avdf_local_attn_bwd_ex(_p(dout), _p(q), _p(k), _p(v), _p(probs), _p(tw), _p(dq), _p(dk), _p(dv), _p(ws), _p(dT),
+                                         B, T, H, hs, window, scale, _stream()), "local_attn_bwd")
+        grads = [None, None]
+        for i, (need, src) in enumerate(((need_rel, ws), (need_tw, dT))):
+            if not need:
+                continue
+            # column sums over the B*T rows of the [B*T, H*window] summand matrix
+            n = H * window
+            main = ctx.main[i]
+            acc = 1 if main is not None else 0
+            dst = main.view(-1) if acc else torch.empty(n, dtype=torch.float32, device=q.device)
+            ws2 = _ws(lib.avdf_masked_colsum_ws(n), q)
+            check(lib.avdf_masked_colsum(_p(src), None, _p(dst), _p(ws2), B * T, n, acc, _stream()), "masked_colsum")
+            grads[i] = None if acc else dst.view(ctx.shapes[i])
+        return dq, dk, dv, None, None, None, grads[0], grads[1]
 
 
 class GlobalAttnFn(torch.autograd.Function):
@@ -789,8 +811,8 @@ class GlobalAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
-def local_attention(q, k, v, kvmask, n_head, window):
-    return LocalAttnFn.apply(q, k, v, kvmask, n_head, window)
+def local_attention(q, k, v, kvmask, n_head, window, rel_pe=None, time_w=None):
+    return LocalAttnFn.apply(q, k, v, kvmask, n_head, window, rel_pe, time_w)
 
 
 def global_attention(q, k, v, kvmask, n_head):

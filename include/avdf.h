@@ -149,6 +149,16 @@ int64_t avdf_local_attn_bwd_ws(int B, int T, int H, int window);
 int avdf_local_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
                         const float* probs, float* dq, float* dk, float* dv, float* ws,
                         int B, int T, int H, int hs, int window, float scale, void* stream);
+/* The same with the optional per-head tables of LocalMaskedMHCA's use_rel_pe / use_time_weight (blocks.py:968-975,
+ * 1188-1189, 1211-1212): rel [H, window] is added to the scores before the softmax, tw [H, window] multiplies the
+ * probabilities after it.  Backward: ws receives dS [B,T,H,window] (column sums over (b,t) = d rel), dT (optional, same
+ * shape) receives p * (dout . v) (column sums = d tw).                                                            */
+int avdf_local_attn_fwd_ex(const float* q, const float* k, const float* v, const float* kvmask, const float* rel,
+                           const float* tw, float* out, float* probs, int B, int T, int H, int hs, int window,
+                           float scale, void* stream);
+int avdf_local_attn_bwd_ex(const float* dout, const float* q, const float* k, const float* v, const float* probs,
+                           const float* tw, float* dq, float* dk, float* dv, float* ws, float* dT, int B, int T,
+                           int H, int hs, int window, float scale, void* stream);
 
 /* ---- global masked attention == MaskedMHCA core (blocks.py:299-309), Tq,Tk <= 256 ------- */
 int avdf_global_attn_fwd(const float* q, const float* k, const float* v, const float* kvmask,

@@ -60,7 +60,7 @@ def ref_model(load_config, C, make_meta_arch, yaml_name, cfg):
     vdim = cfg.get("video_dim", max(8, cfg["input_dim"] // 12))     # "video_dim": 0 = audio-only (BASELINE config 2)
     m.update(video_input_dim=vdim, audio_input_dim=cfg["input_dim"] - vdim,
              max_seq_len=cfg["max_seq_len"], embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"],
-             head_dim=cfg["head_dim"], n_head=cfg["n_head"])
+             head_dim=cfg["head_dim"], n_head=cfg["n_head"], use_rel_pe=bool(cfg.get("use_rel_pe", False)))
     model = make_meta_arch(rc["model_name"], **m)
     return model, rc
 
@@ -256,6 +256,8 @@ def case_train(name, cfg, lens, wseed, xseed, ctx):
     else:
         gkeys += ["interpolator.contraction.down_3.conv_block.conv.weight", "interpolator.conv1.weight",
                   "interpolator.bn1.bias"]
+    if cfg.get("use_rel_pe"):
+        gkeys += ["backbone.stem.1.attn.rel_pe", "backbone.branch.2.attn.rel_pe", "backbone.lh_branch.0.attn.rel_pe"]
     if recon:
         gkeys += ["interpolator.expansion.up_1.conv_transpose.conv.weight",
                   "interpolator.expansion.up_3.conv_transpose.conv.bias",
@@ -715,6 +717,9 @@ def main():
     case_train("train_plain_small", R.make_cfg(variant="plain", **SMALL), [192, 150, 180, 192], 53, 54, ctx)
     case_forward("fwd_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 133], 61, 62, ctx)
     case_train("train_conv_small", R.make_cfg(variant="plainconv", **SMALL), [192, 150, 180, 192], 63, 64, ctx)
+    case_local_attention_tables()
+    case_forward("fwd_relpe_small", R.make_cfg(use_rel_pe=True, **SMALL), [192, 141], 71, 72, ctx)
+    case_train("train_relpe_small", R.make_cfg(use_rel_pe=True, **SMALL), [192, 150, 180, 192], 73, 74, ctx)
     case_forward("fwd_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 140], 41, 42, ctx)
     case_train("train_recon_small", R.make_cfg(variant="recon", **SMALL), [192, 150, 180, 192], 43, 44, ctx)
     print("done")
@@ -813,11 +818,50 @@ def case_train_f64(name, base, cfg, ctx=None):
     np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **store)
 
 
+def case_local_attention_tables():
+    """The reference's LocalMaskedMHCA (blocks.py:883-1224) built with use_rel_pe=True AND use_time_weight=True on seeded
+    weights / inputs: output and the gradients of the input and of both tables.  (use_time_weight is reachable only by
+    constructing blocks directly -- the meta-archs pass use_rel_pe alone -- so it is pinned at the operator level.)"""
+    from libs.modeling.blocks import LocalMaskedMHCA
+    B, C, T, H, W = 2, 32, 48, 4, 7
+    rs = np.random.RandomState(9001)
+    m = LocalMaskedMHCA(C, H, window_size=W, n_qx_stride=1, n_kv_stride=1, use_rel_pe=True, use_time_weight=True)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if k.endswith("norm.weight") or k == "time_weighting":
+            sd[k] = torch.from_numpy((1.0 + 0.2 * rs.standard_normal(v.shape)).astype(np.float32))
+        else:
+            sd[k] = torch.from_numpy((0.3 * rs.standard_normal(v.shape)).astype(np.float32))
+    m.load_state_dict(sd)
+    x = torch.from_numpy(rs.standard_normal((B, C, T)).astype(np.float32)).requires_grad_(True)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    mask[1, 0, 30:] = False
+    out, _ = m(x, mask)
+    w = torch.from_numpy(rs.standard_normal(out.shape).astype(np.float32))
+    (out * w).sum().backward()
+    # the oracle on the same weights
+    xo = x.detach().clone().requires_grad_(True)
+    sdo = {"attn." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oo, _ = R.mhca(sdo, "attn.", xo, mask.float(), xo, mask.float(), xo, mask.float(), H, W, 1)
+    (oo * w).sum().backward()
+    named = dict(m.named_parameters())
+    errs = {"out": maxdiff(out, oo), "dx": maxdiff(x.grad, xo.grad), "drel": maxdiff(named["rel_pe"].grad, sdo["attn.rel_pe"].grad),
+            "dtw": maxdiff(named["time_weighting"].grad, sdo["attn.time_weighting"].grad)}
+    print("[local_attention_tables] oracle vs reference:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert all(v < 2e-5 for v in errs.values())
+    np.savez_compressed(os.path.join(GOLD, "local_attention_tables.npz"), seed=9001, dims=np.array([B, C, T, H, W]),
+                        out=out.detach().numpy(), dx=x.grad.numpy(), drel=named["rel_pe"].grad.numpy(),
+                        dtw=named["time_weighting"].grad.numpy(), dqw=named["query.weight"].grad.numpy())
+
+
 NAMED = {
     "metrics": lambda ctx: case_metrics(),
     "nms_modes": lambda ctx: case_nms_modes(),
     "lr": lambda ctx: case_lr_schedules(),
     "eval_detection": lambda ctx: case_eval_detection(),
+    "rel_pe": lambda ctx: (case_local_attention_tables(),
+                           case_forward("fwd_relpe_small", R.make_cfg(use_rel_pe=True, **SMALL), [192, 141], 71, 72, ctx),
+                           case_train("train_relpe_small", R.make_cfg(use_rel_pe=True, **SMALL), [192, 150, 180, 192], 73, 74, ctx)),
     "train_f64": lambda ctx: (case_train_f64("train_exp10_f64", "train_exp10", R.make_cfg()),
                               case_train_f64("train_audio_exp10_f64", "train_audio_exp10", R.make_cfg(**AUDIO_EXP10)),
                               case_train_f64("train_exp5_f64", "train_exp5", R.make_cfg(**EXP5))),

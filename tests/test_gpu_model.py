@@ -31,7 +31,7 @@ def build(cfg_over, wseed, trained_like=True):
     vdim = cfg.get("video_dim", 8)
     model, _ = build_model(YAML[cfg["variant"]], video_input_dim=vdim, audio_input_dim=cfg["input_dim"] - vdim,
                            max_seq_len=cfg["max_seq_len"], embd_dim=cfg["embd_dim"], fpn_dim=cfg["fpn_dim"],
-                           head_dim=cfg["head_dim"], n_head=cfg["n_head"], **extra)
+                           head_dim=cfg["head_dim"], n_head=cfg["n_head"], use_rel_pe=bool(cfg.get("use_rel_pe", False)), **extra)
     sd = R.synth_state_dict(R.param_shapes(cfg), wseed, trained_like)
     model.load_state_dict(sd, strict=True)
     return model.to("cuda:0"), sd, cfg
@@ -70,6 +70,7 @@ THE_SMALL = dict(variant="the", **SMALL)
 RECON_SMALL = dict(variant="recon", **SMALL)
 PLAIN_SMALL = dict(variant="plain", **SMALL)          # LocPointTransformer + convTransformer backbone
 CONV_SMALL = dict(variant="plainconv", **SMALL)       # LocPointTransformer + conv backbone
+RELPE_SMALL = dict(use_rel_pe=True, **SMALL)          # relative position bias in every local attention
 AUDIO_EXP10 = dict(input_dim=2048, video_dim=0)                  # BASELINE config 2: BYOL-A features only, full-size exp10 architecture
 EXP5 = dict(variant="recon", input_dim=1024, video_dim=256)      # BASELINE config 1: deepfake_exp5.yaml at full size
 
@@ -77,7 +78,8 @@ EXP5 = dict(variant="recon", input_dim=1024, video_dim=256)      # BASELINE conf
 @pytest.mark.parametrize("name,over", [("fwd_small", SMALL), ("fwd_small_init", SMALL), ("fwd_mid", MID),
                                        ("fwd_exp10", {}), ("fwd_audio_exp10", AUDIO_EXP10), ("fwd_exp5", EXP5),
                                        ("fwd_the_small", THE_SMALL),
-                                       ("fwd_recon_small", RECON_SMALL), ("fwd_plain_small", PLAIN_SMALL),
+                                       ("fwd_recon_small", RECON_SMALL), ("fwd_relpe_small", RELPE_SMALL),
+                                       ("fwd_plain_small", PLAIN_SMALL),
                                        ("fwd_conv_small", CONV_SMALL)])
 def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
     g = np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=True)
@@ -118,7 +120,8 @@ def test_forward_and_detections_match_reference_goldens(golden_dir, name, over):
 
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID), ("train_the_small", THE_SMALL),
-                                       ("train_recon_small", RECON_SMALL), ("train_plain_small", PLAIN_SMALL),
+                                       ("train_recon_small", RECON_SMALL), ("train_relpe_small", RELPE_SMALL),
+                                       ("train_plain_small", PLAIN_SMALL),
                                        ("train_conv_small", CONV_SMALL),
                                        ("train_exp10", {}),         # {} = full-size exp10
                                        ("train_audio_exp10", AUDIO_EXP10), ("train_exp5", EXP5)])

@@ -709,3 +709,33 @@ def test_keep_factors_from_uniform_draws(ops):
     assert torch.equal(got.cpu(), ref)
     u2 = torch.rand(8, 256)
     assert torch.equal(ops.dropout_keep(u2.to(dev()), 0.5).cpu(), (u2 >= 0.5).float() / 0.5)
+
+
+def test_local_attention_rel_pe_and_time_weight_match_reference(golden_dir):
+    """LocalMaskedMHCA with use_rel_pe AND use_time_weight (blocks.py:883-1224): output, input gradient and the gradients of
+    both per-head tables against the reference class's own result (tests/golden/local_attention_tables.npz)."""
+    from audio_visual_deepfake_detection_amd.libs.modeling.blocks import LocalMaskedMHCA
+    g = np.load(os.path.join(golden_dir, "local_attention_tables.npz"))
+    B, C, T, H, W = [int(v) for v in g["dims"]]
+    rs = np.random.RandomState(int(g["seed"]))
+    m = LocalMaskedMHCA(C, H, window_size=W, n_qx_stride=1, n_kv_stride=1, use_rel_pe=True, use_time_weight=True)
+    sd = {}
+    for k, v in m.state_dict().items():          # same key order and draws as the generator (reference state_dict order)
+        if k.endswith("norm.weight") or k == "time_weighting":
+            sd[k] = torch.from_numpy((1.0 + 0.2 * rs.standard_normal(v.shape)).astype(np.float32))
+        else:
+            sd[k] = torch.from_numpy((0.3 * rs.standard_normal(v.shape)).astype(np.float32))
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x = torch.from_numpy(rs.standard_normal((B, C, T)).astype(np.float32))
+    w = torch.from_numpy(rs.standard_normal((B, C, T)).astype(np.float32))
+    mask = torch.ones(B, T)
+    mask[1, 30:] = 0
+    xt = x.transpose(1, 2).contiguous().to(dev()).requires_grad_(True)
+    out, _ = m(xt, mask.to(dev()))
+    (out * w.transpose(1, 2).contiguous().to(dev())).sum().backward()
+    close(out.transpose(1, 2), torch.from_numpy(g["out"]), "local attention (rel_pe + time weight)")
+    close(xt.grad.transpose(1, 2), torch.from_numpy(g["dx"]), "dx")
+    close(m.rel_pe.grad, torch.from_numpy(g["drel"]), "d rel_pe", rtol=1e-4)
+    close(m.time_weighting.grad, torch.from_numpy(g["dtw"]), "d time_weighting", rtol=1e-4)
+    close(m.query.weight.grad, torch.from_numpy(g["dqw"]), "d query.weight", rtol=1e-4)

@@ -24,6 +24,7 @@ def synth_inputs(cfg, lens, seed):
 @pytest.mark.parametrize("name,over", [("fwd_small", SMALL), ("fwd_small_init", SMALL), ("fwd_mid", MID),
                                        ("fwd_the_small", dict(variant="the", **SMALL)),
                                        ("fwd_recon_small", dict(variant="recon", **SMALL)),
+                                       ("fwd_relpe_small", dict(use_rel_pe=True, **SMALL)),
                                        ("fwd_plain_small", dict(variant="plain", **SMALL)),
                                        ("fwd_conv_small", dict(variant="plainconv", **SMALL)), ("fwd_exp10", {}),
                                        ("fwd_audio_exp10", dict(input_dim=2048, video_dim=0)),                   # BASELINE config 2
@@ -53,6 +54,7 @@ def test_oracle_forward_and_detections_match_reference(golden_dir, name, over):
 @pytest.mark.parametrize("name,over", [("train_small", SMALL), ("train_mid", MID),
                                        ("train_the_small", dict(variant="the", **SMALL)),
                                        ("train_recon_small", dict(variant="recon", **SMALL)),
+                                       ("train_relpe_small", dict(use_rel_pe=True, **SMALL)),
                                        ("train_plain_small", dict(variant="plain", **SMALL)),
                                        ("train_conv_small", dict(variant="plainconv", **SMALL))])
 def test_oracle_training_losses_and_gradients_match_reference(golden_dir, name, over):
