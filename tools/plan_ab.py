@@ -27,6 +27,15 @@ def fwd_cands():
     return [(t, kg + 8 * db) for t in (1, 2, 3, 6) for kg in (1, 2, 4) if kg <= (1, 2, 4, 4, 2, 4, 4)[t] for db in (0, 1)]
 
 
+def wgrad_cands():
+    return [(sp, kg) for sp in (1, 2, 4, 8, 16, 32) for kg in (1, 2, 4)]
+
+
+# kind 2 = weight gradient: a = token splits, b = K-groups
+WGRAD_SHAPES = [((2, 3, 1, 6144, 256, 3072), wgrad_cands), ((2, 3, 2, 3072, 256, 3072), wgrad_cands), ((2, 3, 1, 12144, 256, 256), wgrad_cands),
+                ((2, 3, 2, 384, 2048, 1024), wgrad_cands), ((2, 3, 2, 768, 1024, 512), wgrad_cands), ((2, 3, 1, 6144, 256, 256), wgrad_cands),
+                ((2, 3, 2, 1536, 512, 256), wgrad_cands), ((2, 3, 2, 192, 256, 2048), wgrad_cands)]
+
 SHAPES = [((4, 1, 1, 6144, 1024, 256), pair_cands), ((4, 1, 1, 6144, 256, 1024), pair_cands), ((4, 1, 1, 18432, 256, 256), pair_cands),
           ((4, 1, 1, 6144, 256, 256), pair_cands), ((0, 1, 1, 6144, 256, 1024), fwd_cands), ((0, 1, 1, 6144, 1024, 256), fwd_cands),
           ((0, 1, 1, 18432, 256, 256), fwd_cands), ((0, 1, 1, 6144, 256, 256), fwd_cands)]
@@ -51,13 +60,14 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--shapes", type=int, default=len(SHAPES))
+    ap.add_argument("--wgrad", action="store_true", help="search the k=3 weight-gradient plans instead of the K=1 classes")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plan_ab.json"))
     args = ap.parse_args()
     chosen, report = {}, []
     base = run(chosen, args.steps, 2)
     print(f"baseline (table in the tree): {base:.1f} clips/s", flush=True)
     cur = base
-    for key, cands in SHAPES[:args.shapes]:
+    for key, cands in (WGRAD_SHAPES if args.wgrad else SHAPES)[:args.shapes]:
         res = {}
         for a, b in cands():
             trial = dict(chosen)
