@@ -46,12 +46,16 @@ def interp_concat_host(streams, out_len, crop=None):
 
 
 class ClipItem(dict):
-    """Item dict with a lazily computed `feats` entry (see the module docstring)."""
+    """Item dict with a lazily computed `feats` entry (see the module docstring).  `max_seq_len` is an attribute, not a
+    key: the keys are exactly the reference's plus `streams` / `crop` (instance attributes of a dict subclass pickle with
+    it, so items survive the DataLoader workers' queues)."""
+
+    max_seq_len = 768
 
     def __missing__(self, key):
         if key != 'feats':
             raise KeyError(key)
-        feats = interp_concat_host(self['streams'], self['_max_seq_len'], self.get('crop'))
+        feats = interp_concat_host(self['streams'], self.max_seq_len, self.get('crop'))
         self['feats'] = feats
         return feats
 
@@ -148,8 +152,8 @@ class _TrainBase(Dataset):
         out = ClipItem({'video_id': rel.replace('.json', '.mp4'), 'streams': streams, 'crop': crop, 'segments': segments,
                         'n_fakes': 0 if segments is None else segments.shape[0], 'labels': labels,
                         'av_labels': torch.tensor(_av_labels(rel)), 'fps': item['fps'], 'duration': item['duration'],
-                        'feat_stride': feat_stride, 'split': item['split'], 'feat_num_frames': num_frames,
-                        '_max_seq_len': self.max_seq_len})
+                        'feat_stride': feat_stride, 'split': item['split'], 'feat_num_frames': num_frames})
+        out.max_seq_len = self.max_seq_len
         if self.return_feats:
             out['feats']
         if self.frame_labels:
@@ -262,7 +266,8 @@ class DeepFakeVideoAudioDatasetInfer3(Dataset):
         out = ClipItem({'video_id': it['id'],
                         'streams': [np.ascontiguousarray(x, np.float32) for x in (v, a1, a2)], 'crop': None,
                         'fps': v.shape[0] / it['duration'], 'duration': it['duration'], 'feat_stride': feat_stride,
-                        'feat_num_frames': feat_stride, '_max_seq_len': self.max_seq_len})
+                        'feat_num_frames': feat_stride})
+        out.max_seq_len = self.max_seq_len
         if self.return_feats:
             out['feats']
         return out

@@ -21,13 +21,22 @@ from torch import nn
 from ... import ops
 
 
-_MASK_CACHE = {}
+import threading as _threading
+
+_tls = _threading.local()          # per thread: an evaluation thread must not clear the cache under a training thread's forward
+
+
+def _mask_cache():
+    c = getattr(_tls, "masks", None)
+    if c is None:
+        c = _tls.masks = {}
+    return c
 
 
 def reset_mask_cache():
     """Called at the start of every network forward: masks of one forward are memoised, never across forwards (the
     engine's static mask buffer is refilled in place between steps)."""
-    _MASK_CACHE.clear()
+    _mask_cache().clear()
 
 
 def _mask_key(mask, stride):
@@ -41,7 +50,7 @@ def prime_mask_pyramid(mask, n_levels, stride=2):
         return
     cur = mask
     for nxt in ops.mask_pyramid(mask, n_levels, stride):
-        _MASK_CACHE[_mask_key(cur, stride)] = (cur, nxt)
+        _mask_cache()[_mask_key(cur, stride)] = (cur, nxt)
         cur = nxt
 
 
@@ -51,10 +60,11 @@ def downsample_mask(mask, stride):
     if stride == 1:
         return mask
     key = _mask_key(mask, stride)
-    hit = _MASK_CACHE.get(key)
+    cache = _mask_cache()
+    hit = cache.get(key)
     if hit is None:
         hit = (mask, mask[:, ::stride].contiguous())          # keeps `mask` alive: its address cannot be recycled
-        _MASK_CACHE[key] = hit
+        cache[key] = hit
     return hit[1]
 
 
