@@ -279,9 +279,12 @@ __global__ __launch_bounds__(1024) void reduce_segments_kernel(const float* __re
   if (col < total) {
     while (col >= sa.first[s + 1]) ++s;
     const int i = col - sa.first[s];
+    // gridDim.y > 1 (accumulating launches only): the rows are split over blockIdx.y, partial sums meet in dst by atomics
+    const int chunk = (nrow + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * chunk, r1 = min(nrow, r0 + chunk);
     for (int j = 0; j < sa.nsrc[s]; ++j) {
       const float* p = ws + sa.src[s][j] + i;
-      for (int r = ph; r < nrow; r += 16) acc += p[(size_t)r * stride];
+      for (int r = r0 + ph; r < r1; r += 16) acc += p[(size_t)r * stride];
     }
   }
   red[ph][cl] = acc;
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(1024) void reduce_segments_kernel(const float* __re
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][cl];
     float* o = sa.dst[s] + (col - sa.first[s]);
-    *o = accumulate ? *o + t : t;
+    if (gridDim.y > 1) atomicAdd(o, t);
+    else *o = accumulate ? *o + t : t;
   }
 }
 
@@ -406,7 +410,9 @@ extern "C" int avdf_reduce_segments(const float* ws, int nrow, int row_stride, i
     sa.first[s + 1] = sa.first[s] + len[s];
   }
   for (int s = nseg; s < kMaxSeg; ++s) { sa.dst[s] = nullptr; sa.len[s] = 0; sa.nsrc[s] = 0; sa.first[s + 1] = sa.first[nseg]; }
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(cdiv(sa.first[nseg], 64)), dim3(1024), 0, (hipStream_t)stream, ws, nrow,
+  // 68 column blocks cover a quarter of the chip: accumulating launches (the engine path) also split the rows 4 ways
+  const int ysplit = (accumulate && nrow >= 128) ? 4 : 1;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(cdiv(sa.first[nseg], 64), ysplit), dim3(1024), 0, (hipStream_t)stream, ws, nrow,
                      row_stride, sa, nseg, accumulate);
   AVDF_CHECK_LAUNCH("reduce_segments");
   return AVDF_OK;
