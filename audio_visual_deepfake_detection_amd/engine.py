@@ -131,6 +131,9 @@ class TrainStep:
                          float(model.video_loss_weight), float(model.loss_normalizer_momentum))
         self.graphs = None
         self._outs = None
+        # everything queued so far on the caller's stream (buffer fills, the RCCL broadcast of the initial weights) must be
+        # visible to the probe, which copies the parameters into the flat buffer on the engine stream
+        self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self._probe_and_flatten()
         torch.cuda.current_stream().wait_stream(self.stream)
