@@ -22,6 +22,7 @@ SIGNATURES = {
     "avdf_softmax_alibi_heads": (I, [P, I, I, I, L, F, P, P]),
     "avdf_gemm_mode": (I, [I]),
     "avdf_gemm_override": (I, [I, I, I]),
+    "avdf_tuned_extra": (I, [P]),
     "avdf_conv1d_fwd_grouped": (I, [I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_data_grouped": (I, [I, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_fwd_residual": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),

@@ -95,6 +95,25 @@ __device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo) {
   lo.x = bf16_bits(l0) | ((unsigned)bf16_bits(l1) << 16); lo.y = bf16_bits(l2) | ((unsigned)bf16_bits(l3) << 16);
 }
 
+__device__ __forceinline__ bf16x8 zero_bf16x8() { return __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
+__device__ __forceinline__ float f4_get(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+// Transposing stage for the split-bf16 backward GEMMs: a thread holds a 4x4 block -- r[j] = 4 consecutive columns of
+// row (4*rq + j) -- and writes, for each of its 4 columns, the 4 consecutive ROW values as one 8-byte run of the hi and
+// of the lo plane (the contraction index becomes the fast LDS axis, which is what the 8-deep MFMA fragments read).
+// item -> (column quad, row quad): 4 lanes x 16 bytes along a global row, 16 row quads per wave = 128 contiguous LDS
+// bytes per column (2-way bank conflicts instead of 16-way for a plain walk).
+template <int C4N, int RQN>
+__device__ __forceinline__ void tq_coord(int q, int& c4, int& rq) {
+  if constexpr (C4N % 4 == 0 && RQN % 16 == 0) {
+    const int l = q & 63, wv = q >> 6;
+    c4 = (wv % (C4N / 4)) * 4 + (l & 3);
+    rq = (wv / (C4N / 4)) * 16 + (l >> 2);
+  } else {
+    c4 = q % C4N;
+    rq = q / C4N;
+  }
+}
+
 // q-th float4 of a [rows][W4 float4] tile -> (row, c4).  A half-wave covers 4 rows x 8 float4 columns, so
 // the 32 lanes that scatter the same component of their float4 into a row-major LDS tile whose row stride is
 // = 1 (mod 32) hit 32 different banks (a plain row-major walk is a 4-way conflict); a wave still reads
@@ -425,16 +444,17 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
 // ------------------------------------------------------------------------------------------
 // data gradient
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB, bool BF3 = false>
 constexpr int dgrad_smem_floats() {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int RA = (BM + KS - 2) / S + 2;
-  constexpr int TILE = round4(round4(RA * (KC + 1)) + KC * BN * KS);
+  // BF3: hi + lo bf16 planes of the g tile [RA][KC+8] and of the TRANSPOSED weight tile [KS][BN][KC+8]
+  constexpr int TILE = BF3 ? round4((RA + BN * KS) * (KC + 8)) : round4(round4(RA * (KC + 1)) + KC * BN * KS);
   return cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
 }
 
 // body of one dgrad workgroup; (bx, by, bz) = the workgroup's coordinates in the (B*tilesT, c-tiles, problems) grid
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB, bool BF3 = false>
 __device__ __forceinline__ void conv_dgrad_body(
     float* __restrict__ smem, const DgradPtrs& ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT,
     int bx, int by, int bz) {
@@ -452,13 +472,19 @@ __device__ __forceinline__ void conv_dgrad_body(
   constexpr int LDA = KC + 1;
   constexpr int LDB = BN * KS;
   constexpr int A4 = KC / 4, B4 = LDB / 4;
-  constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (KC * B4 + NT - 1) / NT;
+  constexpr int NA = (round8(RA) * A4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = KC * LDB;
-  constexpr int TILE = round4(AS + BSZ);
-  static_assert(dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB>() == cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4)), "smem size");
+  // BF3 (split-bf16 operands): g tile as hi / lo planes [RA][LDH]; weight tile transposed to [KS][BN][LDH] so that the
+  // contraction index n is the fast axis of BOTH operands (8-deep fragments = one 16-byte LDS read per lane)
+  constexpr int LDH = KC + 8;
+  constexpr int ASH = RA * LDH, BSH = BN * KS * LDH;
+  constexpr int NQ = KC / 4;                                      // n-quads of a K-tile
+  constexpr int NBQ = (NQ * B4 + NT - 1) / NT;                    // 4x4 blocks of the weight tile per thread
+  constexpr int NB = BF3 ? 4 * NBQ : (KC * B4 + NT - 1) / NT;
+  constexpr int TILE = BF3 ? round4((RA + BN * KS) * LDH) : round4(AS + BSZ);
+  static_assert(dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB, BF3>() == cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4)), "smem size");
   constexpr int KCG = KC / KG;
-  float* As = smem;
-  float* Bs = smem + AS;
+  static_assert(!BF3 || KCG % 16 == 0, "bf16x3 needs 16-deep k-steps per K-group");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kg = wid / WPG, w4 = wid % WPG;
@@ -493,7 +519,7 @@ __device__ __forceinline__ void conv_dgrad_body(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int rr, c4;
-      tile_coord<A4>(tid + i * NT, rr, c4);
+      if (BF3) { rr = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, rr, c4);
       float4 v = zero4();
       if (rr < RA) {
         const int t = tA0 + rr, n = nk0 + c4 * 4;
@@ -504,33 +530,81 @@ __device__ __forceinline__ void conv_dgrad_body(
       }
       ra.v[i] = v;
     }
+    if constexpr (BF3) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * NT;
-      float4 v = zero4();
-      if (q < KC * B4) {
-        const int n = nk0 + q / B4, e = c0 * KS + (q % B4) * 4;
-        if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * Cin * KS + e);
+      for (int ii = 0; ii < NBQ; ++ii) {
+        int c4, nq;
+        tq_coord<B4, NQ>(tid + ii * NT, c4, nq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v = zero4();
+          if (nq < NQ) {
+            const int n = nk0 + nq * 4 + j, e = c0 * KS + c4 * 4;
+            if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * Cin * KS + e);
+          }
+          rb.v[ii * 4 + j] = v;
+        }
       }
-      rb.v[i] = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int q = tid + i * NT;
+        float4 v = zero4();
+        if (q < KC * B4) {
+          const int n = nk0 + q / B4, e = c0 * KS + (q % B4) * 4;
+          if (n < Cout && e < Cin * KS) v = ld4(w + (size_t)n * Cin * KS + e);
+        }
+        rb.v[i] = v;
+      }
     }
   };
   auto store_tile = [&](int boff) {
     float* As = smem + boff;
     float* Bs = As + AS;
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem + boff);
+    __bf16* Al = Ah + ASH;
+    __bf16* Bh = Al + ASH;
+    __bf16* Bl = Bh + BSH;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int rr, c4;
-      tile_coord<A4>(tid + i * NT, rr, c4);
+      if (BF3) { rr = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, rr, c4);
       if (rr < RA) {
-        float* d = As + rr * LDA + c4 * 4;
-        d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+        if (BF3) {
+          uint2 hi, lo;
+          split_bf16x4(ra.v[i], hi, lo);
+          *reinterpret_cast<uint2*>(Ah + rr * LDH + c4 * 4) = hi;
+          *reinterpret_cast<uint2*>(Al + rr * LDH + c4 * 4) = lo;
+        } else {
+          float* d = As + rr * LDA + c4 * 4;
+          d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
+        }
       }
     }
+    if constexpr (BF3) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int q = tid + i * NT;
-      if (q < KC * B4) *reinterpret_cast<float4*>(Bs + (q / B4) * LDB + (q % B4) * 4) = rb.v[i];
+      for (int ii = 0; ii < NBQ; ++ii) {
+        int c4, nq;
+        tq_coord<B4, NQ>(tid + ii * NT, c4, nq);
+        if (nq < NQ) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {                   // column e = (c, k) of the weight row -> LDS row [k][c]
+            const int e = c4 * 4 + jj, cc_ = e / KS, kk_ = e % KS;
+            const float4 v = make_float4(f4_get(rb.v[ii * 4 + 0], jj), f4_get(rb.v[ii * 4 + 1], jj),
+                                         f4_get(rb.v[ii * 4 + 2], jj), f4_get(rb.v[ii * 4 + 3], jj));
+            uint2 hi, lo;
+            split_bf16x4(v, hi, lo);
+            *reinterpret_cast<uint2*>(Bh + (kk_ * BN + cc_) * LDH + nq * 4) = hi;
+            *reinterpret_cast<uint2*>(Bl + (kk_ * BN + cc_) * LDH + nq * 4) = lo;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int q = tid + i * NT;
+        if (q < KC * B4) *reinterpret_cast<float4*>(Bs + (q / B4) * LDB + (q % B4) * 4) = rb.v[i];
+      }
     }
   };
 
@@ -541,6 +615,42 @@ __device__ __forceinline__ void conv_dgrad_body(
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile((kt + 1) * KC);
     const int coff = (DB && (kt & 1)) ? TILE : 0;
+    if constexpr (BF3) {
+      const __bf16* Ah = reinterpret_cast<const __bf16*>(smem + coff);
+      const __bf16* Al = Ah + ASH;
+      const __bf16* Bh = Al + ASH;
+      const __bf16* Bl = Bh + BSH;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+#pragma unroll
+        for (int nn = 0; nn < KCG; nn += 16) {
+          bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int r = arow[mi][k];
+            const int off = (r >= 0 ? r : 0) * LDH + kg * KCG + nn + lh * 8;
+            ah[mi] = r >= 0 ? *reinterpret_cast<const bf16x8*>(Ah + off) : zero_bf16x8();
+            al[mi] = r >= 0 ? *reinterpret_cast<const bf16x8*>(Al + off) : zero_bf16x8();
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int off = (k * BN + (wn * NI + ni) * 32 + li) * LDH + kg * KCG + nn + lh * 8;
+            bh[ni] = *reinterpret_cast<const bf16x8*>(Bh + off);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              floatx16 c_ = acc[mi * NI + ni];
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], c_, 0, 0, 0);
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], c_, 0, 0, 0);
+              c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], c_, 0, 0, 0);
+              acc[mi * NI + ni] = c_;
+            }
+        }
+      }
+    } else {
     const float* Ag = smem + coff + kg * KCG;
     const float* Bg = smem + coff + AS + kg * KCG * LDB;
 #pragma unroll
@@ -562,6 +672,7 @@ __device__ __forceinline__ void conv_dgrad_body(
           for (int ni = 0; ni < NI; ++ni)
             acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
       }
+    }
     }
     if constexpr (DB) {
       if (kt + 1 < nk) store_tile((kt & 1) ? 0 : TILE);
@@ -590,25 +701,26 @@ __device__ __forceinline__ void conv_dgrad_body(
   });
 }
 
-template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false, bool BF3 = false>
 __global__ __launch_bounds__(64 * WM * WN * KG) void conv_dgrad_kernel(
     DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
-  __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB>()];
-  conv_dgrad_body<KS, S, WM, WN, MI, NI, KC, KG, DB>(smem, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, blockIdx.x,
-                                                     blockIdx.y, blockIdx.z);
+  __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB, BF3>()];
+  conv_dgrad_body<KS, S, WM, WN, MI, NI, KC, KG, DB, BF3>(smem, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, blockIdx.x,
+                                                          blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
 // weight gradient (token dimension split over gridDim.z AND over the K-groups of a workgroup)
 // ------------------------------------------------------------------------------------------
-template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool BF3 = false>
 constexpr int wgrad_smem_floats() {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-  return cmax(KT * BM + ((KT - 1) * S + KS) * BN, (KG - 1) * 4 * MI * NI * KS * 1024);
+  // BF3 (K = 1 only): hi + lo bf16 planes of the TRANSPOSED tiles g^T [BM][KT+8] and x^T [BN][KT+8]
+  return cmax(BF3 ? (BM + BN) * (KT + 8) : KT * BM + ((KT - 1) * S + KS) * BN, (KG - 1) * 4 * MI * NI * KS * 1024);
 }
 
 // body of one wgrad workgroup; (bx, by, bz) = coordinates in the (mtiles*problems, c-tiles, token splits) grid, gz = splits
-template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC, bool BF3 = false>
 __device__ __forceinline__ void conv_wgrad_body(
     float* __restrict__ smem, const WgradPtrs& ptrs, int mtiles, int B, int Tin, int Cin, int Tout, int Cout, int act,
     int tilesPerClip, int tilesPerSplit, int accumulate, int bx, int by, int bz, int gz) {
@@ -625,13 +737,28 @@ __device__ __forceinline__ void conv_wgrad_body(
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RX = (KT - 1) * S + KS;
   constexpr int Y4 = BM / 4, X4 = BN / 4;
-  constexpr int NY = (KT * Y4 + NT - 1) / NT, NX = (RX * X4 + NT - 1) / NT;
+  // BF3: both tiles are transposed while staging ([column][token], token-contiguous hi / lo planes) so that the
+  // contraction index t is the fast LDS axis of both MFMA operands
+  static_assert(!BF3 || (KS == 1 && S == 1), "split-bf16 wgrad: K = 1 layers only");
+  constexpr int TQ = KT / 4, LDT = KT + 8;
+  // one index space over the 4x4 blocks of BOTH tiles (g blocks first), so that a 1024-thread workgroup stages one block
+  // per thread instead of two on half of its threads
+  constexpr int YB = TQ * Y4, XB = TQ * X4, NBQ = (YB + XB + NT - 1) / NT;
+  static_assert(!BF3 || YB % 64 == 0, "the g / x split of the block index space is wave-uniform");
+  constexpr int NY = BF3 ? 4 * NBQ : (KT * Y4 + NT - 1) / NT, NX = BF3 ? 1 : (RX * X4 + NT - 1) / NT;
   constexpr int NACC = MI * NI * KS;
   constexpr int YS = KT * BM, XS = RX * BN;
-  static_assert(wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG>() == cmax(YS + XS, (KG - 1) * 4 * NACC * 1024), "smem size");
+  constexpr int YSH = BM * LDT, XSH = BN * LDT;
+  static_assert(wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG, BF3>() ==
+                    cmax(BF3 ? (BM + BN) * LDT : YS + XS, (KG - 1) * 4 * NACC * 1024), "smem size");
   constexpr int KTG = KT / KG;
+  static_assert(!BF3 || KTG % 16 == 0, "bf16x3 needs 16-deep token steps per K-group");
   float* Ys = smem;
   float* Xs = smem + YS;
+  __bf16* Yh = reinterpret_cast<__bf16*>(smem);
+  __bf16* Yl = Yh + YSH;
+  __bf16* Xh = Yl + YSH;
+  __bf16* Xl = Xh + XSH;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kg = wid / WPG, w4 = wid % WPG;
@@ -653,6 +780,36 @@ __device__ __forceinline__ void conv_wgrad_body(
   F4Buf<NX> rx;
   auto load_tile = [&](int g) {
     const int b = g / tilesPerClip, tt0 = (g % tilesPerClip) * KT;
+    if constexpr (BF3) {
+#pragma unroll
+      for (int ii = 0; ii < NBQ; ++ii) {
+        const int q = tid + ii * NT;
+        int c4, tq;
+        if (q < YB) {
+          tq_coord<Y4, TQ>(q, c4, tq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float4 v = zero4();
+            const int t = tt0 + tq * 4 + j, n = n0 + c4 * 4;
+            if (t < Tout && n < Cout) {
+              const size_t row = (size_t)b * Tout + t;
+              v = grad_prologue(dy, mask, ypre, row, row * Cout + n, act);
+            }
+            ry.v[ii * 4 + j] = v;
+          }
+        } else {
+          tq_coord<X4, TQ>(q - YB, c4, tq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float4 v = zero4();
+            const int t = tt0 + tq * 4 + j, c = c0 + c4 * 4;
+            if (q < YB + XB && t < Tin && c < Cin) v = ld4(x + ((size_t)b * Tin + t) * Cin + c);
+            ry.v[ii * 4 + j] = v;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
       const int q = tid + i * NT;
@@ -678,6 +835,27 @@ __device__ __forceinline__ void conv_wgrad_body(
     }
   };
   auto store_tile = [&]() {
+    if constexpr (BF3) {
+#pragma unroll
+      for (int ii = 0; ii < NBQ; ++ii) {
+        const int q = tid + ii * NT;
+        if (q >= YB + XB) continue;
+        int c4, tq;
+        if (q < YB) tq_coord<Y4, TQ>(q, c4, tq); else tq_coord<X4, TQ>(q - YB, c4, tq);
+        __bf16* H = q < YB ? Yh : Xh;
+        __bf16* L = q < YB ? Yl : Xl;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float4 v = make_float4(f4_get(ry.v[ii * 4 + 0], jj), f4_get(ry.v[ii * 4 + 1], jj),
+                                       f4_get(ry.v[ii * 4 + 2], jj), f4_get(ry.v[ii * 4 + 3], jj));
+          uint2 hi, lo;
+          split_bf16x4(v, hi, lo);
+          *reinterpret_cast<uint2*>(H + (c4 * 4 + jj) * LDT + tq * 4) = hi;
+          *reinterpret_cast<uint2*>(L + (c4 * 4 + jj) * LDT + tq * 4) = lo;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
       const int q = tid + i * NT;
@@ -702,9 +880,46 @@ __device__ __forceinline__ void conv_wgrad_body(
   for (int g = gbeg; g < gend; ++g) {
     if (g + 1 < gend) load_tile(g + 1);
     if (do_bias) {
+      if constexpr (BF3) {
+#pragma unroll 4
+        for (int t = 0; t < KT; t += 8) {
+          const bf16x8 h = *reinterpret_cast<const bf16x8*>(Yh + tid * LDT + t);
+          const bf16x8 l = *reinterpret_cast<const bf16x8*>(Yl + tid * LDT + t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum += (float)h[e] + (float)l[e];
+        }
+      } else {
 #pragma unroll 8
-      for (int t = 0; t < KT; ++t) bsum += Ys[t * BM + tid];
+        for (int t = 0; t < KT; ++t) bsum += Ys[t * BM + tid];
+      }
     }
+    if constexpr (BF3) {
+#pragma unroll
+      for (int tl0 = 0; tl0 < KTG; tl0 += 16) {
+        const int tl = kg * KTG + tl0 + lh * 8;
+        bf16x8 ah[MI], al[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int off = ((wm * MI + mi) * 32 + li) * LDT + tl;
+          ah[mi] = *reinterpret_cast<const bf16x8*>(Yh + off);
+          al[mi] = *reinterpret_cast<const bf16x8*>(Yl + off);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int off = ((wn * NI + ni) * 32 + li) * LDT + tl;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Xh + off);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Xl + off);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            floatx16 c_ = acc[mi * NI + ni];
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl, c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh, c_, 0, 0, 0);
+            acc[mi * NI + ni] = c_;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int tl0 = 0; tl0 < KTG; tl0 += 2) {
       const int tl = kg * KTG + tl0;
@@ -721,6 +936,7 @@ __device__ __forceinline__ void conv_wgrad_body(
             acc[(mi * NI + ni) * KS + k] =
                 __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv, acc[(mi * NI + ni) * KS + k], 0, 0, 0);
         }
+    }
     }
     __syncthreads();
     if (g + 1 < gend) {
@@ -755,37 +971,37 @@ __device__ __forceinline__ void conv_wgrad_body(
     }
 }
 
-template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC>
+template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool ATOMIC, bool BF3 = false>
 __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
     WgradPtrs ptrs, int mtiles, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesPerClip,
     int tilesPerSplit, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float smem[wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG>()];
-  conv_wgrad_body<KS, S, WM, WN, MI, NI, KT, KG, ATOMIC>(smem, ptrs, mtiles, B, Tin, Cin, Tout, Cout, act, tilesPerClip,
-                                                         tilesPerSplit, accumulate, blockIdx.x, blockIdx.y, blockIdx.z,
-                                                         gridDim.z);
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG, BF3>()];
+  conv_wgrad_body<KS, S, WM, WN, MI, NI, KT, KG, ATOMIC, BF3>(smem, ptrs, mtiles, B, Tin, Cin, Tout, Cout, act,
+                                                              tilesPerClip, tilesPerSplit, accumulate, blockIdx.x,
+                                                              blockIdx.y, blockIdx.z, gridDim.z);
 }
 
 // K=1 data gradient AND weight gradient of the same layer(s) in ONE launch: workgroups [0, nW) run the wgrad body
 // (token-split, atomics into dw / dbias), workgroups [nW, nW + nD) the dgrad body.  Both read the same dy; issued as
 // one grid they fill the chip together instead of leaving two under-filled launches with a drain between them.
-template <int WM, int WN, int MI, int NI, int KC, int KGD>
+template <int WM, int WN, int MI, int NI, int KC, int KGD, bool BF3 = false>
 __global__ __launch_bounds__(64 * WM * WN * KGD) void conv_bwd_pair_k1_kernel(
     DgradPtrs dp, WgradPtrs wp, int nW, int wgx, int wgy, int wgz, int dgx, int dgy, int mtiles, int B, int T, int Cin,
     int Cout, int act, int tilesT, int tilesPerClip, int tilesPerSplit) {
   constexpr int KG = WM * WN * KGD / 4;          // wgrad K-groups: same workgroup size (4 waves per wgrad K-group)
   static_assert(KG == 1 || KG == 2 || KG == 4, "pair: workgroup of 256 / 512 / 1024 threads");
-  constexpr int SM = cmax(dgrad_smem_floats<1, 1, WM, WN, MI, NI, KC, KGD, false>(),
-                          wgrad_smem_floats<1, 1, 2, 2, 1, 1, 128, KG>());
+  constexpr int SM = cmax(dgrad_smem_floats<1, 1, WM, WN, MI, NI, KC, KGD, false, BF3>(),
+                          wgrad_smem_floats<1, 1, 2, 2, 1, 1, 128, KG, BF3>());
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int id = blockIdx.x;
   if (id < nW) {
     const int bx = id % wgx, by = (id / wgx) % wgy, bz = id / (wgx * wgy);
-    conv_wgrad_body<1, 1, 2, 2, 1, 1, 128, KG, true>(smem, wp, mtiles, B, T, Cin, T, Cout, act, tilesPerClip,
-                                                     tilesPerSplit, 1, bx, by, bz, wgz);
+    conv_wgrad_body<1, 1, 2, 2, 1, 1, 128, KG, true, BF3>(smem, wp, mtiles, B, T, Cin, T, Cout, act, tilesPerClip,
+                                                          tilesPerSplit, 1, bx, by, bz, wgz);
   } else {
     id -= nW;
     const int bx = id % dgx, by = (id / dgx) % dgy, bz = id / (dgx * dgy);
-    conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KGD, false>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
+    conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KGD, false, BF3>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
   }
 }
 
@@ -868,15 +1084,14 @@ struct TilePlan { int tile, kg, db; };
 // ---- measured plans ----------------------------------------------------------------------------------------
 // tools/autotune.py times every (tile, K-groups) / (token-splits, K-groups) choice for the GEMM shapes of a training
 // step on the GPU and writes gemm_tuned.inc; shapes not in the table use the heuristics below.
-struct TunedPlan { int kind, K, stride, M, N, Kred, a, b; };   // kind 0 fwd / 1 dgrad / 3 fwd in bf16x3 mode: (tile, kg + 8*db); 2 wgrad: (splits, kg)
+struct TunedPlan { int kind, K, stride, M, N, Kred, a, b; };   // kind 0 fwd / 1 dgrad / 3 fwd, 6 dgrad in bf16x3 mode: (tile, kg + 8*db); 2 wgrad: (splits, kg); 4 pair / 5 pair in bf16x3 mode: (tile, kg | splits << 3)
 static const TunedPlan kTuned[] = {
 #include "gemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
 // in-situ plan experiments without a rebuild (tools/plan_ab.py): AVDF_TUNED_EXTRA="kind,K,stride,M,N,Kred,a,b;..." rows are
 // looked up before the table (a = -1: pretend the table has no row for the shape -> heuristic plan)
 static TunedPlan g_extra[64];
-static const int g_nextra = [] {
-  const char* e = getenv("AVDF_TUNED_EXTRA");
+static int parse_extra(const char* e) {
   int n = 0;
   while (e && *e && n < 64) {
     TunedPlan t;
@@ -887,7 +1102,8 @@ static const int g_nextra = [] {
     if (*e == ';') ++e;
   }
   return n;
-}();
+}
+static int g_nextra = parse_extra(getenv("AVDF_TUNED_EXTRA"));
 inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, int Kred) {
   for (int i = 0; i < g_nextra; ++i) {
     const TunedPlan* t = &g_extra[i];
@@ -897,8 +1113,9 @@ inline const TunedPlan* tuned_lookup(int kind, int K, int stride, int M, int N, 
     if (t->kind == kind && t->K == K && t->stride == stride && t->M == M && t->N == N && t->Kred == Kred) return t;
   return nullptr;
 }
-// GEMM arithmetic mode: 0 = exact fp32 MFMA (default, what the parity goldens are held against), 1 = split-bf16
-// ("bf16x3") operands in the forward kernels (experimental, avdf_gemm_mode)
+// GEMM arithmetic mode, a bit mask: 0 = exact fp32 MFMA (default, what the parity goldens are held against); bit 0 =
+// split-bf16 ("bf16x3") operands in the forward kernels; bit 1 = split-bf16 operands in the backward kernels (data
+// gradient of every conv, weight gradient of the K = 1 layers) -- both opt-in (avdf_gemm_mode)
 // thread-local: the mode is a launch-time host switch, so a thread that runs inference in bf16x3 cannot change the
 // arithmetic of a training thread that shares the library
 static thread_local int g_gemm_mode = [] { const char* e = getenv("AVDF_GEMM_MODE"); return e ? atoi(e) : 0; }();
@@ -918,7 +1135,8 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
     }
     if (K > 0 && g_override[kind][0] != -2) {          // -2: heuristic only (the tuner's baseline)
       const TunedPlan* t = nullptr;
-      if (kind == 0 && g_gemm_mode == 1) t = tuned_lookup(3, K, stride, B * T, N, Kred);   // kind 3: forward in bf16x3 mode
+      if (kind == 0 && (g_gemm_mode & 1)) t = tuned_lookup(3, K, stride, B * T, N, Kred);   // kind 3: forward in bf16x3 mode
+      if (kind == 1 && (g_gemm_mode & 2)) t = tuned_lookup(6, K, stride, B * T, N, Kred);   // kind 6: dgrad in bf16x3 mode
       if (!t) t = tuned_lookup(kind, K, stride, B * T, N, Kred);
       if (t) return TilePlan{t->a, t->b & 7, (t->b >> 3) & 1};
     }
@@ -1051,7 +1269,7 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     constexpr int RA_ = (BM_ - 1) * S_ + KS_;                                                           \
     constexpr bool DBOK_ = 2 * (RA_ * (KC_ + 1) + BN_ * (KC_ * KS_ + 1) + 8) * 4 <= 150 * 1024;         \
     if constexpr ((KC_ / KG_) % 16 == 0) {                                                              \
-      if (g_gemm_mode == 1) {                                                                           \
+      if (g_gemm_mode & 1) {                                                                            \
         hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
                            dim3(64 * WM_ * WN_ * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, pad,     \
                            ldx, ldw, ldy, xbs, wbs, ybs);                                               \
@@ -1072,7 +1290,7 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
   } while (0)
   if (K == 19 && stride == 1) {          // Emotion2Vec positional grouped conv: 64x64 tile only (the 19-tap B tile is 78 KB)
     // split-bf16 needs 16-deep k-steps per K-group: one K-group in that mode
-    if (plan.kg >= 2 && g_gemm_mode != 1) LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 2); else LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 1);
+    if (plan.kg >= 2 && !(g_gemm_mode & 1)) LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 2); else LAUNCH_FWD(19, 1, 16, 2, 2, 1, 1, 1);
   }
   else if (K == 3 && stride == 1) { AVDF_GEMM_DISPATCH(3, 1, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
   else if (K == 3 && stride == 2) { AVDF_GEMM_DISPATCH(3, 2, 32, 32, 64, 32, 16, 64, 2, LAUNCH_FWD) }
@@ -1188,6 +1406,13 @@ static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin,
     dim3 grid(B * tilesT, cdiv(Cin, BN_), nprob);                                                         \
     constexpr int RAd_ = (BM_ + KS_ - 2) / S_ + 2;                                                        \
     constexpr bool DBOK_ = 2 * (RAd_ * (KC_ + 1) + KC_ * BN_ * KS_ + 8) * 4 <= 150 * 1024;                \
+    if constexpr ((KC_ / KG_) % 16 == 0) {                                                                \
+      if (g_gemm_mode & 2) {                                                                              \
+        hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, false, true>), grid, \
+                           dim3(64 * WM_ * WN_ * KG_), 0, st, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT);           \
+        break;                                                                                            \
+      }                                                                                                   \
+    }                                                                                                     \
     if constexpr (DBOK_) {                                                                                \
       if (plan.db) {                                                                                      \
         hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
@@ -1274,6 +1499,19 @@ static int conv1d_wgrad_launch(const WgradPtrs& ptrs, int nprob, const WgradPlan
                                int Cout, int K, int stride, int act, int accumulate, bool atomic, hipStream_t st) {
 #define LAUNCH_WG(KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_)                                                        \
   do {                                                                                                          \
+    if constexpr (KS_ == 1 && (KT_ / KG_) % 16 == 0) {                                                          \
+      if (g_gemm_mode & 2) {                                                                                    \
+        if (atomic)                                                                                             \
+          hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, true, true>),            \
+                             dim3(p.mtiles * nprob, p.ctiles, p.splits), dim3(256 * KG_), 0, st, ptrs, p.mtiles, B, \
+                             Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);           \
+        else                                                                                                    \
+          hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, false, true>),           \
+                             dim3(p.mtiles * nprob, p.ctiles, p.splits), dim3(256 * KG_), 0, st, ptrs, p.mtiles, B, \
+                             Tin, Cin, Tout, Cout, act, p.tilesPerClip, p.tilesPerSplit, accumulate);           \
+        break;                                                                                                  \
+      }                                                                                                         \
+    }                                                                                                           \
     if (atomic)                                                                                                 \
       hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KT_, KG_, true>),                      \
                          dim3(p.mtiles * nprob, p.ctiles, p.splits), dim3(256 * KG_), 0, st, ptrs, p.mtiles, B, \
@@ -1401,12 +1639,15 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
   T = B * T; B = 1;                                                  // plain GEMM over the token rows
   WgradPlan p = wgrad_plan(B, T, Cin, Cout, 1, n, 1);
   TilePlan plan = pick_tile(B * n, T, Cin, true, 1, 1, Cout);
+  bool bf3_row = false;
   {
     // plans measured for the fused launch (table kind 4: a = dgrad tile, b = K-groups | wgrad token splits << 3)
     int a = -1, b = -1;
-    if (g_override[4][0] >= 0) { a = g_override[4][0]; b = g_override[4][1]; }
+    if (g_override[4][0] >= 0) { a = g_override[4][0]; b = g_override[4][1]; bf3_row = true; }
     else if (g_override[4][0] != -2) {
-      const TunedPlan* t = tuned_lookup(4, 1, 1, n * T, Cin, Cout);
+      const TunedPlan* t = (g_gemm_mode & 2) ? tuned_lookup(5, 1, 1, n * T, Cin, Cout) : nullptr;   // kind 5: pair in bf16x3 mode
+      bf3_row = t != nullptr;
+      if (!t) t = tuned_lookup(4, 1, 1, n * T, Cin, Cout);
       if (t) { a = t->a; b = t->b; }
     }
     if (a >= 0 && a <= 6 && (b >> 3) >= 1) {
@@ -1423,6 +1664,9 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
       p.splits = cdiv(total, p.tilesPerSplit);
     }
   }
+  // split-bf16 mode without a measured row: the 1024-thread variants need > 64 VGPRs there (one workgroup per CU
+  // instead of two); every in-situ search so far (profiles/r02_f_*) picked two K-groups for the big layers
+  if ((g_gemm_mode & 2) && !bf3_row && g_override[1][0] < 0 && plan.kg == 4 && plan.tile != 5) plan.kg = 2;
   if (plan.tile == 6 && plan.kg == 1) plan.kg = 2;   // 64x32 tile: two waves per K-group, the wgrad half needs four per workgroup
   if (!g_pair_mode || !p.small) {
     int rc = conv1d_dgrad_launch(d, n, B, T, Cin, T, Cout, 1, 1, act, st);
@@ -1436,6 +1680,14 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
     const int dgx = B * tilesT, dgy = cdiv(Cin, BN_);                                                               \
     const int wgx = p.mtiles * n, wgy = p.ctiles, wgz = p.splits;                                                   \
     const int nW = wgx * wgy * wgz, nD = dgx * dgy * n;                                                             \
+    if constexpr ((WM_ * WN_ * KG_) % 4 == 0 && (KC_ / KG_) % 16 == 0) {                                            \
+      if (g_gemm_mode & 2) {                                                                                        \
+        hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_, true>), dim3(nW + nD),            \
+                           dim3(64 * WM_ * WN_ * KG_), 0, st, d, g, nW, wgx, wgy, wgz, dgx, dgy, p.mtiles, B, T, Cin, \
+                           Cout, act, tilesT, p.tilesPerClip, p.tilesPerSplit);                                     \
+        break;                                                                                                      \
+      }                                                                                                             \
+    }                                                                                                               \
     if constexpr ((WM_ * WN_ * KG_) % 4 == 0) {                                                                     \
       hipLaunchKernelGGL((conv_bwd_pair_k1_kernel<WM_, WN_, MI_, NI_, KC_, KG_>), dim3(nW + nD), dim3(64 * WM_ * WN_ * KG_), 0,  \
                          st, d, g, nW, wgx, wgy, wgz, dgx, dgy, p.mtiles, B, T, Cin, Cout, act, tilesT,             \
@@ -1450,6 +1702,13 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
   return AVDF_OK;
 }
 
+// tuner hook (tools/plan_search.py): replace the AVDF_TUNED_EXTRA rows of the process ("kind,K,stride,M,N,Kred,a,b;...",
+// NULL or "" = none).  Not for production use: process-wide, not synchronised with concurrent launches.
+extern "C" int avdf_tuned_extra(const char* rows) {
+  g_nextra = parse_extra(rows);
+  return AVDF_OK;
+}
+
 // tuner hook (tools/autotune.py): kind 0 fwd / 1 dgrad: (tile, K-groups); 2 wgrad: (token splits, K-groups); a < 0 = off
 extern "C" int avdf_gemm_override(int kind, int a, int b) {
   AVDF_REQUIRE(kind >= 0 && kind < 5 && kind != 3, "gemm_override: kind in {0, 1, 2, 4}");
@@ -1458,9 +1717,10 @@ extern "C" int avdf_gemm_override(int kind, int a, int b) {
   return AVDF_OK;
 }
 
-// 0 = exact fp32 MFMA (default); 1 = split-bf16 (bf16x3) operands in the forward conv GEMMs.  Per calling thread.
+// bit mask: 0 = exact fp32 MFMA (default); 1 = split-bf16 (bf16x3) operands in the forward conv GEMMs; 2 = in the
+// backward conv GEMMs (dgrad, K = 1 wgrad); 3 = both.  Per calling thread.
 extern "C" int avdf_gemm_mode(int mode) {
-  AVDF_REQUIRE(mode == 0 || mode == 1, "gemm_mode: 0 (fp32) or 1 (bf16x3 forward)");
+  AVDF_REQUIRE(mode >= 0 && mode <= 3, "gemm_mode: bit mask of 1 (bf16x3 forward) and 2 (bf16x3 backward)");
   g_gemm_mode = mode;
   return AVDF_OK;
 }

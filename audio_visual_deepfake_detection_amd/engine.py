@@ -74,7 +74,7 @@ class TrainStep:
 
     def __init__(self, model, batch, streams_shapes, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8,
                  clip_grad_l2norm=1.0, ema_decay=0.999, use_graph=True, process_group=None, max_gt=8, wgrad_side=False,
-                 fwd_bf16x3=False, deterministic=False, overlap=True):
+                 fwd_bf16x3=False, bwd_bf16x3=False, deterministic=False, overlap=True):
         assert next(model.parameters()).is_cuda
         self.model = model.train()
         self.dev = next(model.parameters()).device
@@ -86,6 +86,7 @@ class TrainStep:
         self.use_graph = use_graph
         self.wgrad_side = wgrad_side        # weight-gradient GEMMs on a second stream (joined at the end of backward)
         self.fwd_bf16x3 = fwd_bf16x3        # forward GEMMs with split-bf16 operands (faster; gradients ~1e-3 instead of 1e-5)
+        self.bwd_bf16x3 = bwd_bf16x3        # backward GEMMs (dgrad, K = 1 wgrad) with split-bf16 operands (opt-in as well)
         self.deterministic = deterministic
         self.overlap = overlap
         self.step_count = 0
@@ -259,7 +260,8 @@ class TrainStep:
     # --------------------------------------------------------------------------------------------
     def _stage_a(self):
         ops.interp_concat_batched(self.stream_bufs, self.x)
-        with ops.gemm_mode(1 if self.fwd_bf16x3 else ops.current_gemm_mode()):
+        # the mode a layer's forward is issued under also selects the arithmetic of its backward kernels (bit 1)
+        with ops.gemm_mode(ops.current_gemm_mode() | (1 if self.fwd_bf16x3 else 0) | (2 if self.bwd_bf16x3 else 0)):
             outs = self._forward()
         st = torch.cuda.current_stream().cuda_stream
         radius, center = self.loss_cfg[0], self.loss_cfg[1]

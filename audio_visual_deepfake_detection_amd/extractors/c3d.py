@@ -89,7 +89,7 @@ class C3DVideoEncoder(nn.Module):
         st = torch.cuda.current_stream().cuda_stream
         B, T, H, W, _ = x.shape
         assert H == W and H % 48 == 0, "the pooling chain (3,2,2,2,2) must end at 2x2"
-        bf3 = 1 if (ops.INFER_BF16X3 or ops.current_gemm_mode() == 1) else 0      # opt-in (exact fp32 by default)
+        bf3 = 1 if (ops.INFER_BF16X3 or (ops.current_gemm_mode() & 1)) else 0      # opt-in (exact fp32 by default)
         check(lib.avdf_conv3d_mode(bf3), "conv3d_mode")          # split-bf16 operands for the Cin >= 16 layers
         for (wp, b), (_, pool) in zip(self._packed[0], self._plan):
             cout, cin = wp.shape[3], wp.shape[4]

@@ -174,10 +174,16 @@ class Conv1dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, mask, ypre)
         ctx.cfg = (B, Tin, Cin, Tout, Cout, K, stride, act, bias is not None)
         ctx.main = (_main_grad(w0), _main_grad(b0))
+        ctx.gmode = current_gemm_mode()
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        with _IssueMode(getattr(ctx, "gmode", 0)):
+            return Conv1dFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, w, mask, ypre = ctx.saved_tensors
         B, Tin, Cin, Tout, Cout, K, stride, act, has_bias = ctx.cfg
         dy = dy.contiguous()
@@ -225,9 +231,10 @@ class Conv1dFn(torch.autograd.Function):
 
 BWD_PAIR = True      # K=1 layers: data + weight gradient in one launch (avdf_conv1d_bwd_pair_grouped) on the engine path
 
-# Arithmetic mode of the forward conv GEMMs: 0 = exact fp32 MFMA (the default EVERYWHERE: training, model.eval(), the
-# extractors -- what every parity fixture is held against), 1 = split-bf16 operands ("bf16x3", ~5e-6 relative error,
-# 1.3-1.9x faster).  The mode is per THREAD on both sides of the C ABI (threading.local here, thread_local in the
+# Arithmetic mode of the conv GEMMs, a bit mask: 0 = exact fp32 MFMA (the default EVERYWHERE: training, model.eval(), the
+# extractors -- what every parity fixture is held against); bit 0 = split-bf16 operands ("bf16x3", ~5e-6 relative error,
+# 1.3-1.9x faster) in the forward kernels; bit 1 = the same in the backward kernels of the layers whose forward was issued
+# under it (data gradients, K = 1 weight gradients).  The mode is per THREAD on both sides of the C ABI (threading.local here, thread_local in the
 # library), so an evaluation / prefetch thread cannot change the arithmetic of a training thread.
 import threading as _threading
 
@@ -242,7 +249,7 @@ def current_gemm_mode():
 
 
 def set_gemm_mode(mode):
-    """Arithmetic mode of the forward conv GEMMs launched by THIS thread from now on (see avdf_gemm_mode)."""
+    """Arithmetic mode (bit mask, see above) of the conv GEMMs launched by THIS thread from now on (see avdf_gemm_mode)."""
     check(lib.avdf_gemm_mode(int(mode)), "gemm_mode")
     _tls.mode = int(mode)
 
@@ -267,7 +274,26 @@ def infer_mode(bf16x3=None):
     """Arithmetic mode of the inference-only paths: exact fp32 unless bf16x3 is asked for (argument, `INFER_BF16X3`, or
     AVDF_INFER_BF16X3=1); an enclosing `gemm_mode(1)` is kept."""
     want = INFER_BF16X3 if bf16x3 is None else bool(bf16x3)
-    return gemm_mode(1 if want else current_gemm_mode())
+    return gemm_mode((current_gemm_mode() | 1) if want else current_gemm_mode())
+
+
+class _IssueMode:
+    """Backward launches run on the autograd worker thread, whose library mode is that thread's own default: carry the
+    mode the layer's FORWARD was issued under (saved in ctx) across, so `gemm_mode(3)` around a forward pass selects the
+    arithmetic of that pass's backward GEMMs (bit 1) as well, and nothing else in the process."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = current_gemm_mode()
+        if self.prev != self.mode:
+            set_gemm_mode(self.mode)
+
+    def __exit__(self, *a):
+        if self.prev != self.mode:
+            set_gemm_mode(self.prev)
+        return False
 
 
 class _ExactGemm:
@@ -324,6 +350,7 @@ class Conv1dResidualFn(torch.autograd.Function):
         ctx.cfg = (B, Tin, Cin, Tin, Cout, K, 1, ACT_NONE, bias is not None)
         ctx.main = (_main_grad(w0), _main_grad(b0))
         ctx.smain, ctx.sshape = _main_grad(scale), scale.shape
+        ctx.gmode = current_gemm_mode()
         return out
 
     @staticmethod
@@ -340,6 +367,7 @@ class Conv1dResidualFn(torch.autograd.Function):
         check(lib.avdf_affine_residual_bwd(_p(dout), None, _p(h), None, _p(sc), _p(keep), None, _p(dh), _p(ds), _p(ws), B, Tout,
                                            Cout, acc, _stream()), "affine_residual_bwd")
         proxy = _CtxProxy((x, w, mask, None), ctx.cfg, ctx.main, ctx.needs_input_grad[0:3] + (False,) * 3)
+        proxy.gmode = getattr(ctx, "gmode", 0)
         dx, dw, db = Conv1dFn.backward(proxy, dh)[0:3]
         return dx, dw, db, None, dout, None if (ds is None or acc) else ds.view(ctx.sshape), None
 
@@ -375,10 +403,16 @@ class Conv1dGroup3Fn(torch.autograd.Function):
         ctx.save_for_backward(*xs, *ws_)
         ctx.cfg = (B, T, Cin, Cout, K, has_bias)
         ctx.main = ([_main_grad(t) for t in ws0], [_main_grad(t) for t in bs0])
+        ctx.gmode = current_gemm_mode()
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, d0, d1, d2):
+        with _IssueMode(getattr(ctx, "gmode", 0)):
+            return Conv1dGroup3Fn._backward(ctx, d0, d1, d2)
+
+    @staticmethod
+    def _backward(ctx, d0, d1, d2):
         sv = ctx.saved_tensors
         xs, ws_ = list(sv[0:3]), list(sv[3:6])
         B, T, Cin, Cout, K, has_bias = ctx.cfg
@@ -444,8 +478,10 @@ class ConvTranspose1dFn(torch.autograd.Function):
         T2 = 2 * T
         st = _stream()
         raw = torch.empty((B, T2, Co), dtype=x.dtype, device=x.device)
-        check(lib.avdf_conv1d_bwd_data(_p(x), _p(w), None, None, _p(raw), B, T2, Co, T, Ci, 3, 2, ACT_NONE, st),
-              "conv_transpose1d_fwd")
+        ctx.gmode = current_gemm_mode()
+        with _IssueMode(2 if (ctx.gmode & 1) else 0):      # the forward pass IS a data-gradient kernel: swap the mode bits
+            check(lib.avdf_conv1d_bwd_data(_p(x), _p(w), None, None, _p(raw), B, T2, Co, T, Ci, 3, 2, ACT_NONE, st),
+                  "conv_transpose1d_fwd")
         y = torch.empty_like(raw)
         check(lib.avdf_bias_mask_fwd(_p(raw), _p(bias), _p(mask_out), _p(y), B * T2, Co, st), "bias_mask_fwd")
         ctx.save_for_backward(x, w, mask_out)
@@ -463,15 +499,17 @@ class ConvTranspose1dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.avdf_conv1d_fwd(_p(g), _p(w), None, None, _p(dx), None, B, T2, Co, T, Ci, 3, 2, ACT_NONE, st),
-                  "conv_transpose1d_dx")
+            with _IssueMode(1 if (getattr(ctx, "gmode", 0) & 2) else 0):
+                check(lib.avdf_conv1d_fwd(_p(g), _p(w), None, None, _p(dx), None, B, T2, Co, T, Ci, 3, 2, ACT_NONE, st),
+                      "conv_transpose1d_dx")
         mw, mb = ctx.main
         acc = 1 if mw is not None else 0
         if ctx.needs_input_grad[1]:
             dw = mw.view(w.shape) if acc else torch.empty_like(w)
             ws = _ws(lib.avdf_conv1d_bwd_weight_ws(B, T, Co, Ci, 3), x)
-            check(lib.avdf_conv1d_bwd_weight(_p(x), _p(g), None, None, _p(dw), None, _p(ws), B, T2, Co, T, Ci, 3, 2,
-                                             ACT_NONE, acc, st), "conv_transpose1d_dw")
+            with _IssueMode(0):
+                check(lib.avdf_conv1d_bwd_weight(_p(x), _p(g), None, None, _p(dw), None, _p(ws), B, T2, Co, T, Ci, 3, 2,
+                                                 ACT_NONE, acc, st), "conv_transpose1d_dw")
         if has_bias and ctx.needs_input_grad[2]:
             accb = 1 if mb is not None else 0
             db = mb.view(Co) if accb else torch.empty(Co, dtype=w.dtype, device=w.device)

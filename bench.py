@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--bf16x3-fwd", action="store_true",
                     help="training forward GEMMs with split-bf16 operands (759 vs 712 clips/s; losses agree to 1e-6, gradient "
                          "elements to ~5e-3 instead of 1e-4 -- not the parity-checked default)")
+    ap.add_argument("--bf16x3-bwd", action="store_true",
+                    help="training backward GEMMs (data gradients, K = 1 weight gradients) with split-bf16 operands; opt-in "
+                         "like --bf16x3-fwd (tolerance stated in tests/test_gpu_engine.py)")
     ap.add_argument("--bf16x3", action="store_true",
                     help="infer / e2e modes: split-bf16 forward GEMMs (~5e-6 relative error; exact fp32 is the default)")
     ap.add_argument("--workload", default="av", choices=["av", "audio"],
@@ -270,7 +273,8 @@ def main():
     if args.mode == "train":
         eng = TrainStep(model, B, STREAMS, lr=cfg["opt"]["learning_rate"] * world,        # train.py:60 LR rule
                         weight_decay=cfg["opt"]["weight_decay"], clip_grad_l2norm=cfg["train_cfg"]["clip_grad_l2norm"],
-                        use_graph=not args.no_graph, process_group=pg, wgrad_side=args.wgrad_side, fwd_bf16x3=args.bf16x3_fwd)
+                        use_graph=not args.no_graph, process_group=pg, wgrad_side=args.wgrad_side, fwd_bf16x3=args.bf16x3_fwd,
+                        bwd_bf16x3=args.bf16x3_bwd)
     else:
         eng = InferStep(model, B, STREAMS, use_graph=not args.no_graph, bf16x3=args.bf16x3)
     from audio_visual_deepfake_detection_amd import dp
@@ -338,7 +342,7 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    bf3 = (args.mode != "train" and args.bf16x3)
+    bf3 = (args.mode != "train" and args.bf16x3) or (args.mode == "train" and args.bf16x3_bwd)   # arithmetic of the dominant class
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if bf3 else PEAK_F32_MFMA_TFLOPS
     if args.mode == "train":
         use_graph = eng.use_graph
@@ -383,6 +387,7 @@ def main():
             "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": pmc_traffic(tag) if args.mode == "train" else None,
             "mfma_util": pmc_mfma_util(tag) if args.mode == "train" else None,
+            **({"frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)} if bf3 else {}),
             "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
             "flops_per_launch": round(fl / cnt),
             "all_mfma_kernels": {"achieved": round(tot_f / tot_t / 1e12, 2), "frac": round(tot_f / tot_t / 1e12 / peak, 4),
@@ -409,7 +414,7 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": 768,
                        "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
                        "fwd_gemm": ("bf16x3" if ((args.mode != "train" and args.bf16x3) or args.bf16x3_fwd) else "f32"),
-                       "bwd_gemm": "f32",
+                       "bwd_gemm": ("bf16x3 (dgrad, K=1 wgrad)" if args.bf16x3_bwd else "f32"),
                        "dead_params_skipped": len(getattr(eng, "dead", []))},
         }
         if roof is not None:

@@ -79,6 +79,9 @@ int avdf_bwd_pair_mode(int mode);
  * buffer); 2 wgrad: (token splits, K-groups); 4 backward pair: (dgrad tile, K-groups | wgrad splits << 3)); a = -1
  * restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only.                                      */
 int avdf_gemm_override(int kind, int a, int b);
+/* Tuner hook (tools/plan_search.py): replace the process's AVDF_TUNED_EXTRA plan rows ("kind,K,stride,M,N,Kred,a,b;...";
+ * kinds 3 / 5 / 6 = forward / backward pair / dgrad in split-bf16 mode); NULL or "" clears them.                    */
+int avdf_tuned_extra(const char* rows);
 
 /* avdf_conv1d_fwd_ex with explicit batch strides (floats): batch b reads x + b*xbs, multiplies by the weight matrix
  * w + b*wbs and writes y + b*ybs -- every head of an attention layer (Q_h.K_h^T, P_h.V_h^T) in one launch
@@ -87,10 +90,12 @@ int avdf_conv1d_fwd_strided(const float* x, const float* w, const float* bias, f
                             int Tout, int Cout, int K, int stride, int pad, int ldx, int ldw, int ldy,
                             int64_t xbs, int64_t wbs, int64_t ybs, int act, void* stream);
 
-/* Arithmetic mode of the forward conv GEMMs: 0 = exact fp32 MFMA (default; what the parity fixtures are held
- * against), 1 = split-bf16 operands ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate,
- * ~2^-17 relative error per product).  The switch is THREAD-LOCAL host state read at launch time: it applies to the
- * launches the calling thread issues afterwards and never to another thread's.                                 */
+/* Arithmetic mode of the conv GEMMs, a bit mask: 0 = exact fp32 MFMA (default; what the parity fixtures are held
+ * against); bit 0 = split-bf16 operands ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate,
+ * ~2^-17 relative error per product) in the forward kernels; bit 1 = the same in the backward kernels (data gradient
+ * of every conv, weight gradient of the K = 1 layers incl. the fused pair launch).  The switch is THREAD-LOCAL host
+ * state read at launch time: it applies to the launches the calling thread issues afterwards and never to another
+ * thread's.                                                                                                      */
 int avdf_gemm_mode(int mode);
 
 /* General forward form for the frozen extractors: explicit zero padding `pad` (0 = the "valid" convs of the

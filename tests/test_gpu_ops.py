@@ -504,12 +504,16 @@ def test_conv1d_forward_bf16x3_mode(ops, case):
     # (plans whose K-group slice is not a multiple of 16 keep the exact kernel even in mode 1, so y0 may equal y1)
 
 
+@pytest.mark.parametrize("mode", [0, 3])
 @pytest.mark.parametrize("shape", [(2, 200, 96, 136, 3, 1), (3, 192, 256, 64, 1, 1), (2, 96, 64, 40, 3, 2), (1, 520, 1024, 256, 1, 1)])
-def test_conv1d_every_gemm_plan(ops, shape):
+def test_conv1d_every_gemm_plan(ops, shape, mode):
     """Every (tile, K-groups, double-buffer) plan the tuner may select, forced through avdf_gemm_override, for the
-    forward and the data-gradient kernels, against float64."""
+    forward and the data-gradient kernels, against float64 -- in exact fp32 (mode 0) and with split-bf16 operands in
+    both directions (mode 3: ~1e-5 of the output scale; plans whose K-group slice is not a multiple of 16 keep the exact
+    kernel)."""
     from audio_visual_deepfake_detection_amd._lib import lib, check
     B, T, Cin, Cout, K, s = shape
+    rt = RTOL if mode == 0 else 3e-5
     Tout = (T + 2 * (K // 2) - K) // s + 1
     x, w = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, K, seed=2, scale=(Cin * K) ** -0.5)
     dy = rnd(B, Tout, Cout, seed=3)
@@ -519,6 +523,7 @@ def test_conv1d_every_gemm_plan(ops, shape):
     xd, wd, dyd = g32(x), g32(w), g32(dy)
     st = torch.cuda.current_stream().cuda_stream
     try:
+        ops.set_gemm_mode(mode)
         for tile in range(7):
             for kg in (1, 2, 4):
                 if kg > (1, 2, 4, 4, 2, 4, 4)[tile]:
@@ -532,19 +537,22 @@ def test_conv1d_every_gemm_plan(ops, shape):
                                               K, s, 0, st), "fwd")
                     check(lib.avdf_conv1d_bwd_data(dyd.data_ptr(), wd.data_ptr(), None, None, dx.data_ptr(), B, T, Cin, Tout, Cout,
                                                    K, s, 0, st), "dgrad")
-                    close(y, ref, f"fwd tile {tile} kg {kg} db {db}")
-                    close(dx, x64.grad, f"dgrad tile {tile} kg {kg} db {db}")
+                    close(y, ref, f"fwd tile {tile} kg {kg} db {db}", rtol=rt)
+                    close(dx, x64.grad, f"dgrad tile {tile} kg {kg} db {db}", rtol=rt)
     finally:
+        ops.set_gemm_mode(0)
         for k in range(3):
             check(lib.avdf_gemm_override(k, -1, -1), "override")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("n,B,T,Cin,Cout,act", [(1, 2, 200, 64, 136, 1), (3, 3, 192, 256, 256, 0), (1, 8, 96, 1024, 256, 0),
                                                 (2, 1, 12, 256, 1024, 2)])
-def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
+def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act, mode):
     """avdf_conv1d_bwd_pair_grouped (K=1 dgrad + accumulating wgrad in one launch) for every dgrad plan the tuner may
-    select, against the two separate entry points (dx bit-identical: same workgroup body) and against float64."""
+    select, against the two separate entry points (dx bit-identical: same workgroup body) and against float64; mode 2 =
+    the split-bf16 backward kernels."""
     import ctypes
     from audio_visual_deepfake_detection_amd._lib import lib, check
     tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -568,7 +576,9 @@ def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
     base_db = [g32(rnd(Cout, seed=60 + i)) for i in range(n)]
     # separate launches (the reference point)
     dx_sep = [torch.empty(B, T, Cin, device=dev()) for _ in range(n)]
+    rt = RTOL if mode == 0 else 3e-5
     try:
+        ops.set_gemm_mode(mode)
         check(lib.avdf_gemm_override(4, -2, -2), "override")      # the pair's own table rows off: plans come from kind 1 / 2
         for tile in range(7):
             for kg in (1, 2, 4):
@@ -585,7 +595,7 @@ def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
                 for i in range(n):
                     g = gref(i)
                     assert torch.equal(dx[i], dx_sep[i]), f"dx differs from the separate dgrad launch (tile {tile} kg {kg})"
-                    close(dx[i], (g @ ws_[i][:, :, 0].double()).cpu(), f"dx tile {tile} kg {kg}")
+                    close(dx[i], (g @ ws_[i][:, :, 0].double()).cpu(), f"dx tile {tile} kg {kg}", rtol=rt)
                     close(dw[i][:, :, 0] - base_dw[i][:, :, 0],
                           torch.einsum("btn,btc->nc", g, xs[i].double()).cpu(), f"dw tile {tile} kg {kg}", rtol=2e-4)
                     close(db[i] - base_db[i], g.sum((0, 1)).cpu(), f"db tile {tile} kg {kg}", rtol=2e-4)
@@ -599,6 +609,7 @@ def test_conv1d_bwd_pair_every_plan(ops, n, B, T, Cin, Cout, act):
         for i in range(n):
             close(dw[i][:, :, 0], torch.einsum("btn,btc->nc", gref(i), xs[i].double()).cpu(), "dw (pair off)", rtol=2e-4)
     finally:
+        ops.set_gemm_mode(0)
         check(lib.avdf_bwd_pair_mode(1), "mode")
         for k in (0, 1, 2, 4):
             check(lib.avdf_gemm_override(k, -1, -1), "override")
