@@ -11,6 +11,9 @@ run train_b32 --steps 20 --warmup 5 --batch 32 --no-cpu-baseline
 run train_b50 --steps 20 --warmup 5 --batch 50 --no-cpu-baseline
 run train_audio_b8 --steps 40 --warmup 10 --workload audio --no-cpu-baseline
 run train_b8_bf16x3fwd --steps 40 --warmup 10 --bf16x3-fwd --no-cpu-baseline
+run train_b8_bf16x3 --steps 40 --warmup 10 --bf16x3-fwd --bf16x3-bwd --no-cpu-baseline
+run train_b32_bf16x3 --steps 20 --warmup 5 --batch 32 --bf16x3-fwd --bf16x3-bwd --no-cpu-baseline
+run train_b50_bf16x3 --steps 20 --warmup 5 --batch 50 --bf16x3-fwd --bf16x3-bwd --no-cpu-baseline
 run infer_b8 --mode infer --steps 40 --warmup 10
 run infer_b32 --mode infer --steps 20 --warmup 5 --batch 32 --no-cpu-baseline
 run infer_b8_bf16x3 --mode infer --steps 40 --warmup 10 --bf16x3 --no-cpu-baseline

@@ -19,17 +19,20 @@ STREAMS = [(768, 256), (383, 2048), (1535, 768)]
 MAXKG = (1, 2, 4, 4, 2, 4, 4)
 
 
+TILES = [1, 2, 3, 5, 6]         # --tiles; 0 = 128x128 and 4 = 256x64 (2x2 accumulator tiles per wave) are large-batch candidates
+
+
 def pair_cands(splits=(4, 8, 16)):
-    return [(t, kg | (sp << 3)) for t in (1, 2, 3, 5, 6) for kg in (1, 2, 4) if kg <= MAXKG[t] and not (t == 6 and kg == 1)
+    return [(t, kg | (sp << 3)) for t in TILES for kg in (1, 2, 4) if kg <= MAXKG[t] and not (t == 6 and kg == 1)
             for sp in splits]
 
 
 def tile_cands():
-    return [(t, kg) for t in (1, 2, 3, 6) for kg in (1, 2, 4) if kg <= MAXKG[t]]
+    return [(t, kg) for t in TILES if t != 5 for kg in (1, 2, 4) if kg <= MAXKG[t]]
 
 
 def fwd_cands():
-    return [(t, kg + 8 * db) for t in (1, 2, 3, 6) for kg in (1, 2, 4) if kg <= MAXKG[t] for db in (0, 1)]
+    return [(t, kg + 8 * db) for t in TILES if t != 5 for kg in (1, 2, 4) if kg <= MAXKG[t] for db in (0, 1)]
 
 
 def shapes(batch, bf3, fwd=False):
@@ -51,9 +54,12 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bf3", action="store_true")
     ap.add_argument("--shapes", type=int, default=99)
+    ap.add_argument("--tiles", default="1,2,3,5,6", help="output tiles tried (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x128, 4: 256x64, 5: 32x32, 6: 64x32)")
+    ap.add_argument("--splits", default="4,8,16", help="wgrad token splits tried for the fused K=1 backward")
     ap.add_argument("--fwd", action="store_true", help="search the forward plans (kind 0, or 3 with --bf3) instead of the backward ones")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plan_search.json"))
     args = ap.parse_args()
+    TILES[:] = [int(x) for x in args.tiles.split(",")]
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model0, _ = build_model("deepfake_exp10.yaml")             # pristine CPU copy: TrainStep rebinds the parameters it is given
@@ -90,7 +96,7 @@ def main():
     print(f"baseline (table in the tree): {cur:.1f} clips/s", flush=True)
     for key, cands in shapes(args.batch, args.bf3, args.fwd)[:args.shapes]:
         res = {}
-        for a, b in cands():
+        for a, b in (cands(tuple(int(x) for x in args.splits.split(","))) if cands is pair_cands else cands()):
             trial = dict(chosen)
             trial[key] = (a, b)
             res[(a, b)] = measure(trial)
