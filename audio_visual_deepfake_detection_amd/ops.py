@@ -58,7 +58,7 @@ def _timed(tag, flops, fn, shape=None):
     s.record()
     r = fn()
     e.record()
-    _prof.append((tag, flops, s, e))
+    _prof.append((tag, flops, s, e, shape))
     return r
 
 

@@ -371,7 +371,7 @@ def main():
     else:
         eng.graph = graphs
     agg = {}
-    for tag, fl, s, e in recs:
+    for tag, fl, s, e, _shape in recs:
         a = agg.setdefault(tag, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += s.elapsed_time(e) * 1e-3

@@ -48,12 +48,52 @@ def shapes(batch, bf3, fwd=False):
             ((dk, 3, 1, M, 256, 256), tile_cands), ((dk, 3, 2, M, 256, 256), tile_cands)]
 
 
+def ranked_shapes(model0, batch, bf3, dev):
+    """Table keys of every GEMM launch of one eager step, heaviest first: [(key, candidate fn, ms per step)]."""
+    from audio_visual_deepfake_detection_amd import ops
+    model = copy.deepcopy(model0).to(dev)
+    eng = TrainStep(model, batch, STREAMS, lr=1e-4, use_graph=False, fwd_bf16x3=bf3, bwd_bf16x3=bf3)
+    for b in range(batch):
+        for dst in eng.streams[b]:
+            dst.normal_()
+        eng.ngt[b] = 0
+    eng.gt.zero_()
+    eng.gt[0, 0, 0], eng.gt[0, 0, 1], eng.ngt[0] = 100.0, 260.0, 1
+    eng.step()
+    torch.cuda.synchronize()
+    ops.profile_begin()
+    eng.step()
+    torch.cuda.synchronize()
+    recs = ops.profile_end()
+    agg = {}
+    for tag, fl, s, e, shape in recs:
+        if shape is None:
+            continue
+        kind, K, st, B, Tin, Cin, Cout, n = shape
+        Tout = (Tin + 2 * (K // 2) - K) // st + 1
+        if kind == "fwd":
+            key, c = ((3 if bf3 else 0), K, st, B * n * Tout, Cout, Cin), fwd_cands
+        elif kind == "dgrad":
+            key, c = ((6 if bf3 else 1), K, st, B * n * Tin, Cin, Cout), tile_cands
+        elif kind == "pair":
+            key, c = ((5 if bf3 else 4), 1, 1, B * n * Tin, Cin, Cout), pair_cands
+        else:
+            continue                                    # k=3 weight gradients: tools/plan_ab.py --wgrad
+        a = agg.setdefault(key, [c, 0.0])
+        a[1] += s.elapsed_time(e)
+    del eng, model
+    torch.cuda.empty_cache()
+    return sorted(((k, c, ms) for k, (c, ms) in agg.items()), key=lambda r: -r[2])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--bf3", action="store_true")
     ap.add_argument("--shapes", type=int, default=99)
+    ap.add_argument("--auto", type=int, default=0, help="search the N heaviest GEMM shapes of a profiled eager step (skipping --skip)")
+    ap.add_argument("--skip", type=int, default=0, help="with --auto: skip the first K shapes of the ranking (searched before)")
     ap.add_argument("--tiles", default="1,2,3,5,6", help="output tiles tried (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x128, 4: 256x64, 5: 32x32, 6: 64x32)")
     ap.add_argument("--splits", default="4,8,16", help="wgrad token splits tried for the fused K=1 backward")
     ap.add_argument("--fwd", action="store_true", help="search the forward plans (kind 0, or 3 with --bf3) instead of the backward ones")
@@ -91,10 +131,16 @@ def main():
         torch.cuda.empty_cache()
         return args.batch / best
 
+    todo = shapes(args.batch, args.bf3, args.fwd)[:args.shapes]
+    if args.auto:
+        ranked = ranked_shapes(model0, args.batch, args.bf3, dev)
+        for k, c, ms in ranked[:args.skip + args.auto]:
+            print(f"  {ms:7.3f} ms/step  {k}", flush=True)
+        todo = [(k, c) for k, c, _ in ranked[args.skip:args.skip + args.auto]]
     chosen, report = {}, []
     cur = measure(chosen)
     print(f"baseline (table in the tree): {cur:.1f} clips/s", flush=True)
-    for key, cands in shapes(args.batch, args.bf3, args.fwd)[:args.shapes]:
+    for key, cands in todo:
         res = {}
         for a, b in (cands(tuple(int(x) for x in args.splits.split(","))) if cands is pair_cands else cands()):
             trial = dict(chosen)
