@@ -716,7 +716,9 @@ template <int KS, int S, int WM, int WN, int MI, int NI, int KT, int KG, bool BF
 constexpr int wgrad_smem_floats() {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   // BF3 (K = 1 only): hi + lo bf16 planes of the TRANSPOSED tiles g^T [BM][KT+8] and x^T [BN][KT+8]
-  return cmax(BF3 ? (BM + BN) * (KT + 8) : KT * BM + ((KT - 1) * S + KS) * BN, (KG - 1) * 4 * MI * NI * KS * 1024);
+  // k = 3: the epilogue parks WM*32 rows of the [n][(c, k)] result tile in LDS (row-contiguous gradient writes)
+  return cmax(cmax(BF3 ? (BM + BN) * (KT + 8) : KT * BM + ((KT - 1) * S + KS) * BN, (KG - 1) * 4 * MI * NI * KS * 1024),
+              KS > 1 ? WM * 32 * (BN * KS + 4) : 0);
 }
 
 // body of one wgrad workgroup; (bx, by, bz) = coordinates in the (mtiles*problems, c-tiles, token splits) grid, gz = splits
@@ -749,7 +751,7 @@ __device__ __forceinline__ void conv_wgrad_body(
   constexpr int NACC = MI * NI * KS;
   constexpr int YS = KT * BM, XS = RX * BN;
   constexpr int YSH = BM * LDT, XSH = BN * LDT;
-  static_assert(wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG, BF3>() ==
+  static_assert(wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG, BF3>() >=
                     cmax(BF3 ? (BM + BN) * LDT : YS + XS, (KG - 1) * 4 * NACC * 1024), "smem size");
   constexpr int KTG = KT / KG;
   static_assert(!BF3 || KTG % 16 == 0, "bf16x3 needs 16-deep token steps per K-group");
@@ -946,10 +948,54 @@ __device__ __forceinline__ void conv_wgrad_body(
   }
   if (do_bias && n0 + tid < Cout) atomicAdd(dbias + n0 + tid, bsum);
   kgroup_reduce<NACC, KG>(acc, smem, kg, w4, lane);
-  if (kg != 0) return;
-
   float* o = out + ((!ATOMIC && gz > 1) ? (size_t)bz * Cout * Cin * KS : 0);
   const bool add = accumulate && gz == 1;
+  if constexpr (KS > 1) {
+    // k = 3: an accumulator register holds elements (n, c, k) that lie KS floats apart in dw[n][c][k], so adding them
+    // straight from the registers is a strided wave-instruction -- a third of each 64-byte atomic request used, and
+    // float atomics run at the memory side at ~1.3 TB/s only for CONTIGUOUS 256-byte wave-instructions
+    // (MI355X_MICROARCH.md, Global float atomics).  The tile goes through LDS as rows [n][(c, k)] instead (a row of the
+    // tile is BN*KS consecutive floats of dw) and every wave adds / stores 64 consecutive floats; a launch without a
+    // token split owns its elements and uses a plain float4 read-add-store (stores run at ~6 TB/s).
+    constexpr int ROWF = BN * KS, LDR = ROWF + 4, ROWS = WM * 32;
+    static_assert(ROWS * LDR <= wgrad_smem_floats<KS, S, WM, WN, MI, NI, KT, KG, BF3>(), "epilogue tile fits");
+    const size_t ldw = (size_t)Cin * KS;
+    const int rowlen = min(ROWF, (Cin - c0) * KS);                  // valid floats of a tile row
+#pragma unroll
+    for (int p = 0; p < MI; ++p) {
+      __syncthreads();                                               // LDS free: K-group reduction / previous pass read
+      if (kg == 0) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+              smem[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDR + ((wn * NI + ni) * 32 + li) * KS + k] =
+                  acc[(p * NI + ni) * KS + k][r];
+      }
+      __syncthreads();
+      if (ATOMIC && gz > 1) {
+        for (int q = tid; q < ROWS * ROWF; q += NT) {
+          const int rr = q / ROWF, e = q % ROWF;
+          const int n = n0 + ((rr >> 5) * MI + p) * 32 + (rr & 31);
+          if (n < Cout && e < rowlen) atomicAdd(o + (size_t)n * ldw + (size_t)c0 * KS + e, smem[rr * LDR + e]);
+        }
+      } else {
+        for (int q = tid; q < ROWS * (ROWF / 4); q += NT) {
+          const int rr = q / (ROWF / 4), e = (q % (ROWF / 4)) * 4;
+          const int n = n0 + ((rr >> 5) * MI + p) * 32 + (rr & 31);
+          if (n >= Cout || e >= rowlen) continue;                    // Cin % 4 == 0: a float4 is all valid or all not
+          float4 v = *reinterpret_cast<const float4*>(smem + rr * LDR + e);
+          float4* d = reinterpret_cast<float4*>(o + (size_t)n * ldw + (size_t)c0 * KS + e);
+          if (ATOMIC || add) { const float4 g = *d; v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w; }
+          *d = v;
+        }
+      }
+    }
+    return;
+  }
+  if (kg != 0) return;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1548,6 +1594,7 @@ extern "C" int avdf_conv1d_bwd_weight(const float* dy, const float* x, const flo
   AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_weight: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
   AVDF_REQUIRE(Tout == (Tin + 2 * (K / 2) - K) / stride + 1, "conv1d_bwd_weight: Tout inconsistent");
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws) && (!ypre || aligned16(ypre)), "conv1d_bwd_weight: 16-byte alignment");
+  AVDF_REQUIRE(K == 1 || aligned16(dw), "conv1d_bwd_weight: dw of a k=3 layer must be 16-byte aligned (float4 row writes)");
   hipStream_t st = (hipStream_t)stream;
   if (K == 1 && stride == 1) { Tin = Tout = B * Tin; B = 1; }      // plain GEMM over the token rows
   const WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, 1, stride);
@@ -1603,6 +1650,7 @@ extern "C" int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, con
     g.dy[i] = dy[j]; g.x[i] = x[j]; g.out[i] = dw[j];
     g.mask[i] = mask ? mask[j] : nullptr; g.ypre[i] = ypre ? ypre[j] : nullptr; g.dbias[i] = dbias ? dbias[j] : nullptr;
     AVDF_REQUIRE(aligned16(g.dy[i]) && aligned16(g.x[i]) && aligned16(g.ypre[i]), "conv1d_bwd_weight_grouped: 16-byte alignment");
+    AVDF_REQUIRE(K == 1 || aligned16(g.out[i]), "conv1d_bwd_weight_grouped: dw of a k=3 layer must be 16-byte aligned");
   }
   if (K == 1 && stride == 1) { Tin = Tout = B * Tin; B = 1; }
   WgradPlan p = wgrad_plan(B, Tout, Cin, Cout, K, n, stride);
