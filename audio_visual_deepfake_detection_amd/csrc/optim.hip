@@ -8,7 +8,23 @@ namespace {
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t n) {
   __shared__ float red[256];
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // 16-byte loads, two independent accumulators per thread, two loads in flight per iteration
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float s1 = 0.f;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+      const float4 a = x4[i], b = x4[i + stride];
+      s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+    if (i < n4) { const float4 a = x4[i]; s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+    s += s1;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += t * t; }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {

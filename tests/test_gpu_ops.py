@@ -359,6 +359,9 @@ def test_adamw_ema_kernel(ops):
         check(lib.avdf_adamw_ema(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(),
                                  nsq.data_ptr(), hp.data_ptr(), n, 0.9, 0.999, 1e-8, 0.05, 1.0, 0.999, st), "adamw")
         close(nsq.sqrt(), gn.view(1), "grad norm")
+        nsq2 = torch.zeros(1, device=dev())                     # a view that is not 16-byte aligned takes the scalar path
+        check(lib.avdf_sumsq(gd[1:].data_ptr(), nsq2.data_ptr(), ws.data_ptr(), n - 1, st), "sumsq")
+        close(nsq2.sqrt(), g[1:].norm().view(1), "grad norm (unaligned)")
     close(p, pr.detach(), "adamw params", rtol=1e-5)
     close(ema, ema_ref, "ema", rtol=1e-5)
 

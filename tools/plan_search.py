@@ -31,6 +31,10 @@ def tile_cands():
     return [(t, kg) for t in TILES if t != 5 for kg in (1, 2, 4) if kg <= MAXKG[t]]
 
 
+def wgrad_cands():
+    return [(sp, kg) for sp in (1, 2, 4, 8, 16, 32) for kg in (1, 2)]
+
+
 def fwd_cands():
     return [(t, kg + 8 * db) for t in TILES if t != 5 for kg in (1, 2, 4) if kg <= MAXKG[t] for db in (0, 1)]
 
@@ -77,8 +81,10 @@ def ranked_shapes(model0, batch, bf3, dev):
             key, c = ((6 if bf3 else 1), K, st, B * n * Tin, Cin, Cout), tile_cands
         elif kind == "pair":
             key, c = ((5 if bf3 else 4), 1, 1, B * n * Tin, Cin, Cout), pair_cands
+        elif kind == "wgrad" and K == 3:
+            key, c = (2, K, st, B * Tout, Cout * n, Cin), wgrad_cands
         else:
-            continue                                    # k=3 weight gradients: tools/plan_ab.py --wgrad
+            continue
         a = agg.setdefault(key, [c, 0.0])
         a[1] += s.elapsed_time(e)
     del eng, model
@@ -93,6 +99,7 @@ def main():
     ap.add_argument("--bf3", action="store_true")
     ap.add_argument("--shapes", type=int, default=99)
     ap.add_argument("--auto", type=int, default=0, help="search the N heaviest GEMM shapes of a profiled eager step (skipping --skip)")
+    ap.add_argument("--kinds", default="", help="with --auto: only table kinds in this comma list (e.g. 2 = k=3 weight gradients)")
     ap.add_argument("--skip", type=int, default=0, help="with --auto: skip the first K shapes of the ranking (searched before)")
     ap.add_argument("--tiles", default="1,2,3,5,6", help="output tiles tried (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x128, 4: 256x64, 5: 32x32, 6: 64x32)")
     ap.add_argument("--splits", default="4,8,16", help="wgrad token splits tried for the fused K=1 backward")
@@ -134,6 +141,8 @@ def main():
     todo = shapes(args.batch, args.bf3, args.fwd)[:args.shapes]
     if args.auto:
         ranked = ranked_shapes(model0, args.batch, args.bf3, dev)
+        if args.kinds:
+            ranked = [r for r in ranked if r[0][0] in [int(x) for x in args.kinds.split(",")]]
         for k, c, ms in ranked[:args.skip + args.auto]:
             print(f"  {ms:7.3f} ms/step  {k}", flush=True)
         todo = [(k, c) for k, c, _ in ranked[args.skip:args.skip + args.auto]]
