@@ -13,6 +13,7 @@
 //           dx += LN_a'(dz) summed over the branches that share the input; the per-channel parameter partials
 //           of a workgroup go to a workspace row that avdf_reduce_segments folds (no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -303,7 +304,10 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 constexpr int kTile = 32, kWaves = 8;
 // backward: 16-token tiles -> twice the workgroups, 76 KB of LDS each (2 per CU): the three branches of a tile are
 // processed one after the other, so co-resident workgroups are what hides the load latency
-constexpr int kTileB = 16, kWavesB = 8;
+constexpr int kWavesB = 8;
+// tile sizes are host-side launch parameters (AVDF_CHAIN_TILE_F in {16, 32}, AVDF_CHAIN_TILE_B in {8, 16, 32}: in-situ A/B)
+static const int g_tile_f = [] { const char* e = getenv("AVDF_CHAIN_TILE_F"); const int v = e ? atoi(e) : kTile; return v == 16 ? 16 : 32; }();
+static const int g_tile_b = [] { const char* e = getenv("AVDF_CHAIN_TILE_B"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 32) ? v : 16; }();
 
 }  // namespace
 
@@ -328,23 +332,21 @@ extern "C" int avdf_chain_fwd(const float* const* x, const float* const* gamma_a
     a.u[i] = u[i]; a.y[i] = y[i]; a.sa[i] = stats_a[i]; a.sb[i] = stats_b[i];
   }
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 1) {
-    constexpr int TO = kTile;
-    const int tiles = cdiv(Tout, TO);
-    hipLaunchKernelGGL((chain_fwd_kernel<1, TO, kWaves>), dim3(B * tiles, 3), dim3(64 * kWaves),
-                       (size_t)((TO - 1) + 3) * C * sizeof(float), st, a, mask, B, Tin, Tout, C, eps, tiles);
-  } else {
-    constexpr int TO = kTile / 2;
-    const int tiles = cdiv(Tout, TO);
-    hipLaunchKernelGGL((chain_fwd_kernel<2, TO, kWaves>), dim3(B * tiles, 3), dim3(64 * kWaves),
-                       (size_t)((TO - 1) * 2 + 3) * C * sizeof(float), st, a, mask, B, Tin, Tout, C, eps, tiles);
-  }
+#define LAUNCH_CF(S_, TO_)                                                                                          \
+  do {                                                                                                              \
+    const int tiles = cdiv(Tout, TO_);                                                                              \
+    hipLaunchKernelGGL((chain_fwd_kernel<S_, TO_, kWaves>), dim3(B * tiles, 3), dim3(64 * kWaves),                  \
+                       (size_t)((TO_ - 1) * S_ + 3) * C * sizeof(float), st, a, mask, B, Tin, Tout, C, eps, tiles); \
+  } while (0)
+  if (stride == 1) { if (g_tile_f == 16) LAUNCH_CF(1, 16); else LAUNCH_CF(1, 32); }
+  else { if (g_tile_f == 16) LAUNCH_CF(2, 8); else LAUNCH_CF(2, 16); }
+#undef LAUNCH_CF
   AVDF_CHECK_LAUNCH("chain_fwd");
   return AVDF_OK;
 }
 
-extern "C" int64_t avdf_chain_bwd_ws(int B, int Tin, int C) { return (int64_t)B * cdiv(Tin, kTileB) * 21 * C; }
-extern "C" int avdf_chain_bwd_rows(int B, int Tin) { return B * cdiv(Tin, kTileB); }
+extern "C" int64_t avdf_chain_bwd_ws(int B, int Tin, int C) { return (int64_t)B * cdiv(Tin, g_tile_b) * 21 * C; }
+extern "C" int avdf_chain_bwd_rows(int B, int Tin) { return B * cdiv(Tin, g_tile_b); }
 
 extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, const float* const* stats_b,
                               const float* const* x, const float* const* stats_a, const float* const* gamma_a,
@@ -380,16 +382,16 @@ extern "C" int avdf_chain_bwd_res(const float* const* dy, const float* const* u,
     AVDF_REQUIRE(aligned16(a.dres[i]) && (!a.dres[i] || ((store_mask >> i) & 1)), "chain_bwd: dres must be 16-byte aligned and belong to a closing branch");
   }
   hipStream_t st = (hipStream_t)stream;
-  const int tiles = cdiv(Tin, kTileB);
-  if (stride == 1) {
-    constexpr int RU = kTileB + 2;
-    hipLaunchKernelGGL((chain_bwd_kernel<1, kTileB, kWavesB>), dim3(B * tiles), dim3(64 * kWavesB),
-                       (size_t)(RU + kWavesB * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
-  } else {
-    constexpr int RU = kTileB / 2 + 2;
-    hipLaunchKernelGGL((chain_bwd_kernel<2, kTileB, kWavesB>), dim3(B * tiles), dim3(64 * kWavesB),
-                       (size_t)(RU + kWavesB * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask);
-  }
+  const int tiles = cdiv(Tin, g_tile_b);
+#define LAUNCH_CB(S_, TI_)                                                                                            \
+  do {                                                                                                                \
+    constexpr int RU = TI_ / S_ + 2;                                                                                  \
+    hipLaunchKernelGGL((chain_bwd_kernel<S_, TI_, kWavesB>), dim3(B * tiles), dim3(64 * kWavesB),                     \
+                       (size_t)(RU + kWavesB * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask); \
+  } while (0)
+  if (stride == 1) { if (g_tile_b == 8) LAUNCH_CB(1, 8); else if (g_tile_b == 32) LAUNCH_CB(1, 32); else LAUNCH_CB(1, 16); }
+  else { if (g_tile_b == 8) LAUNCH_CB(2, 8); else if (g_tile_b == 32) LAUNCH_CB(2, 32); else LAUNCH_CB(2, 16); }
+#undef LAUNCH_CB
   AVDF_CHECK_LAUNCH("chain_bwd");
   return AVDF_OK;
 }
