@@ -199,7 +199,7 @@ def main():
                     help="weight-gradient GEMMs on a second HIP stream (measured slower inside hipGraphs: 558 vs 611 clips/s)")
     ap.add_argument("--branch-streams", action="store_true", help="run the q/k/v chains on three HIP streams")
     ap.add_argument("--bf16x3-fwd", action="store_true",
-                    help="training forward GEMMs with split-bf16 operands (759 vs 712 clips/s; losses agree to 1e-6, gradient "
+                    help="training forward GEMMs with split-bf16 operands (807 vs 760 clips/s; losses agree to 1e-6, gradient "
                          "elements to ~5e-3 instead of 1e-4 -- not the parity-checked default)")
     ap.add_argument("--bf16x3-bwd", action="store_true",
                     help="training backward GEMMs (data gradients, K = 1 weight gradients) with split-bf16 operands; opt-in "
