@@ -179,8 +179,28 @@ __device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// LDS floats of a forward workgroup (same arithmetic as inside the kernel) and the waves-per-SIMD target that keeps as many
+// workgroups co-resident as LDS allows: the vectorised K = 1 variant holds float4 fragments, and without the hint the
+// compiler spends 6-8 more VGPRs than the co-residency of the 512- / 1024-thread plans can afford
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3, bool DB>
+constexpr int fwd_smem_floats() {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32, RA = (BM - 1) * S + KS, KB = KC * KS;
+  constexpr bool VEC = (KS == 1) && !BF3 && ((KC / KG) % 8 == 0);
+  constexpr int LDA = VEC ? KC + 4 : KC + 1, LDB = VEC ? KB + 4 : KB + 1;
+  constexpr int TILE = round4(BF3 ? (RA * (KC + 8) + BN * (KB + 8)) : (round4(RA * LDA) + BN * LDB));
+  return cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
+}
+template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3, bool DB>
+constexpr int fwd_waves_per_simd() {
+  constexpr bool VEC = (KS == 1) && !BF3 && ((KC / KG) % 8 == 0);
+  constexpr int NT = 64 * WM * WN * KG;
+  constexpr int wgs = (160 * 1024) / (fwd_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, BF3, DB>() * 4);
+  constexpr int w = wgs * NT / 256;
+  return (VEC && NT >= 512 && KG < 16) ? (w > 8 ? 8 : (w < 1 ? 1 : w)) : 1;      // 16 K-groups: the hint would spill
+}
+
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool BF3 = false, bool DB = false>
-__global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
+__global__ __launch_bounds__(64 * WM * WN * KG, (fwd_waves_per_simd<KS, S, WM, WN, MI, NI, KC, KG, BF3, DB>())) void conv_fwd_kernel(
     FwdPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT, int P, int ldx, int ldw, int ldy,
     long xbs, long wbs, long ybs) {
   // xbs / wbs / ybs: batch strides of x, w, y in floats (default Tin*ldx, 0, Tout*ldy; attention heads use
@@ -199,9 +219,14 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
   constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int RA = (BM - 1) * S + KS;
-  constexpr int LDA = KC + 1;
+  // VEC (K = 1, exact fp32): rows padded by 4 floats instead of 1, so that staging is one ds_write_b128 per float4 and a
+  // lane fetches FOUR k-steps of its operand row with one ds_read_b128 (16 lanes x 16 B at a 272-byte row stride cover
+  // the 64 banks exactly once).  MFMA j of an 8-deep step then contracts k = {cc + j, cc + 4 + j}: the pairing is the
+  // same for A and B, and a sum does not care about the order of its terms.  4x fewer LDS instructions per MFMA.
+  constexpr bool VEC = (KS == 1) && !BF3 && ((KC / KG) % 8 == 0);
+  constexpr int LDA = VEC ? KC + 4 : KC + 1;
   constexpr int KB = KC * KS;
-  constexpr int LDB = KB + 1;
+  constexpr int LDB = VEC ? KB + 4 : KB + 1;
   constexpr int A4 = KC / 4, B4 = KB / 4;
   constexpr int NA = (round8(RA) * A4 + NT - 1) / NT, NB = (BN * B4 + NT - 1) / NT;
   constexpr int AS = round4(RA * LDA), BSZ = BN * LDB;
@@ -215,6 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
   // barrier per K-stage instead of two (long-K problems; costs co-residency, so the plan decides)
   constexpr int TILE = round4(BF3 ? (ASH + BSH) : (AS + BSZ));
   constexpr int SM = cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
+  static_assert(SM == fwd_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, BF3, DB>(), "smem size");
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* As = smem;
   float* Bs = smem + AS;
@@ -242,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int row, c4;
-      if (BF3) { row = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, row, c4);
+      if (BF3 || VEC) { row = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, row, c4);
       float4 v = zero4();
       if (row < RA) {
         const int c = c0 + c4 * 4;
@@ -254,7 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int row, c4;
-      if (BF3) { row = (tid + i * NT) / B4; c4 = (tid + i * NT) % B4; } else tile_coord<B4>(tid + i * NT, row, c4);
+      if (BF3 || VEC) { row = (tid + i * NT) / B4; c4 = (tid + i * NT) % B4; } else tile_coord<B4>(tid + i * NT, row, c4);
       float4 v = zero4();
       if (row < BN) {
         const int n = n0 + row, e = c0 * KS + c4 * 4;
@@ -273,13 +299,15 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int row, c4;
-      if (BF3) { row = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, row, c4);
+      if (BF3 || VEC) { row = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, row, c4);
       if (row < RA) {
         if (BF3) {
           uint2 hi, lo;
           split_bf16x4(ra.v[i], hi, lo);
           *reinterpret_cast<uint2*>(Ah + row * LDAH + c4 * 4) = hi;
           *reinterpret_cast<uint2*>(Al + row * LDAH + c4 * 4) = lo;
+        } else if (VEC) {
+          *reinterpret_cast<float4*>(As + row * LDA + c4 * 4) = ra.v[i];
         } else {
           float* d = As + row * LDA + c4 * 4;
           d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
@@ -289,7 +317,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int row, c4;
-      if (BF3) { row = (tid + i * NT) / B4; c4 = (tid + i * NT) % B4; } else tile_coord<B4>(tid + i * NT, row, c4);
+      if (BF3 || VEC) { row = (tid + i * NT) / B4; c4 = (tid + i * NT) % B4; } else tile_coord<B4>(tid + i * NT, row, c4);
       if (row < BN) {
         if (BF3) {
           uint2 hi, lo;
@@ -307,6 +335,8 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
               reinterpret_cast<unsigned short*>(Bl)[row * LDBH + kk_ * KC + cc_] = l[j];
             }
           }
+        } else if (VEC) {
+          *reinterpret_cast<float4*>(Bs + row * LDB + c4 * 4) = rb.v[i];
         } else {
           float* d = Bs + row * LDB + c4 * 4;
           d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
@@ -359,6 +389,24 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void conv_fwd_kernel(
               acc[mi * NI + ni] = c_;
             }
         }
+      }
+    } else if constexpr (VEC) {
+      const float* Ag = As + kg * KCG + lh * 4;
+      const float* Bg = Bs + kg * KCG + lh * 4;
+#pragma unroll
+      for (int cc = 0; cc < KCG; cc += 8) {
+        float4 a4[MI], b4[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a4[mi] = *reinterpret_cast<const float4*>(Ag + ((wm * MI + mi) * 32 + li) * LDA + cc);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b4[ni] = *reinterpret_cast<const float4*>(Bg + ((wn * NI + ni) * 32 + li) * LDB + cc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(a4[mi], j), f4_get(b4[ni], j), acc[mi * NI + ni], 0, 0, 0);
       }
     } else {
     const float* Ag = As + kg * KCG;
@@ -1313,7 +1361,7 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     const int tilesT = cdiv(Tout, BM_);                                                                 \
     dim3 grid(B * tilesT, cdiv(Cout, BN_), nprob);                                                      \
     constexpr int RA_ = (BM_ - 1) * S_ + KS_;                                                           \
-    constexpr bool DBOK_ = 2 * (RA_ * (KC_ + 1) + BN_ * (KC_ * KS_ + 1) + 8) * 4 <= 150 * 1024;         \
+    constexpr bool DBOK_ = 2 * (RA_ * (KC_ + 4) + BN_ * (KC_ * KS_ + 4) + 8) * 4 <= 150 * 1024;         \
     if constexpr ((KC_ / KG_) % 16 == 0) {                                                              \
       if (g_gemm_mode & 1) {                                                                            \
         hipLaunchKernelGGL((conv_fwd_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, true>), grid,        \
