@@ -497,7 +497,9 @@ constexpr int dgrad_smem_floats() {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int RA = (BM + KS - 2) / S + 2;
   // BF3: hi + lo bf16 planes of the g tile [RA][KC+8] and of the TRANSPOSED weight tile [KS][BN][KC+8]
-  constexpr int TILE = BF3 ? round4((RA + BN * KS) * (KC + 8)) : round4(round4(RA * (KC + 1)) + KC * BN * KS);
+  // VECA (K = 1, fp32): g rows padded by 4 floats (16-byte staging stores and fragment reads, see conv_fwd_kernel)
+  constexpr bool VECA = (KS == 1) && (S == 1) && !BF3 && ((KC / KG) % 8 == 0);
+  constexpr int TILE = BF3 ? round4((RA + BN * KS) * (KC + 8)) : round4(round4(RA * (KC + (VECA ? 4 : 1))) + KC * BN * KS);
   return cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
 }
 
@@ -517,7 +519,8 @@ __device__ __forceinline__ void conv_dgrad_body(
   constexpr int WPG = WM * WN, NT = 64 * WPG * KG;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32, P = KS / 2;
   constexpr int RA = (BM + KS - 2) / S + 2;
-  constexpr int LDA = KC + 1;
+  constexpr bool VECA = (KS == 1) && (S == 1) && !BF3 && ((KC / KG) % 8 == 0);
+  constexpr int LDA = VECA ? KC + 4 : KC + 1;
   constexpr int LDB = BN * KS;
   constexpr int A4 = KC / 4, B4 = LDB / 4;
   constexpr int NA = (round8(RA) * A4 + NT - 1) / NT;
@@ -567,7 +570,7 @@ __device__ __forceinline__ void conv_dgrad_body(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int rr, c4;
-      if (BF3) { rr = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, rr, c4);
+      if (BF3 || VECA) { rr = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, rr, c4);
       float4 v = zero4();
       if (rr < RA) {
         const int t = tA0 + rr, n = nk0 + c4 * 4;
@@ -616,13 +619,15 @@ __device__ __forceinline__ void conv_dgrad_body(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int rr, c4;
-      if (BF3) { rr = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, rr, c4);
+      if (BF3 || VECA) { rr = (tid + i * NT) / A4; c4 = (tid + i * NT) % A4; } else tile_coord<A4>(tid + i * NT, rr, c4);
       if (rr < RA) {
         if (BF3) {
           uint2 hi, lo;
           split_bf16x4(ra.v[i], hi, lo);
           *reinterpret_cast<uint2*>(Ah + rr * LDH + c4 * 4) = hi;
           *reinterpret_cast<uint2*>(Al + rr * LDH + c4 * 4) = lo;
+        } else if (VECA) {
+          *reinterpret_cast<float4*>(As + rr * LDA + c4 * 4) = ra.v[i];
         } else {
           float* d = As + rr * LDA + c4 * 4;
           d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
@@ -698,6 +703,30 @@ __device__ __forceinline__ void conv_dgrad_body(
             }
         }
       }
+    } else if constexpr (VECA) {
+      // the g operand: four k-steps per ds_read_b128; MFMA j contracts n = {nn + j, nn + 4 + j} (the weight rows follow)
+      const float* Ag = smem + coff + kg * KCG + lh * 4;
+      const float* Bg = smem + coff + AS + (kg * KCG + lh * 4) * LDB;
+#pragma unroll
+      for (int nn = 0; nn < KCG; nn += 8) {
+        float4 a4[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int r = arow[mi][0];
+          a4[mi] = r >= 0 ? *reinterpret_cast<const float4*>(Ag + r * LDA + nn) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float bv[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bv[ni] = Bg[(nn + j) * LDB + (wn * NI + ni) * 32 + li];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(a4[mi], j), bv[ni], acc[mi * NI + ni], 0, 0, 0);
+        }
+      }
     } else {
     const float* Ag = smem + coff + kg * KCG;
     const float* Bg = smem + coff + AS + kg * KCG * LDB;
@@ -750,7 +779,7 @@ __device__ __forceinline__ void conv_dgrad_body(
 }
 
 template <int KS, int S, int WM, int WN, int MI, int NI, int KC, int KG, bool DB = false, bool BF3 = false>
-__global__ __launch_bounds__(64 * WM * WN * KG) void conv_dgrad_kernel(
+__global__ __launch_bounds__(64 * WM * WN * KG, ((KS == 1 && !BF3 && !DB && WM == 1 && WN == 4 && KG == 4) ? 8 : 1)) void conv_dgrad_kernel(
     DgradPtrs ptrs, int B, int Tin, int Cin, int Tout, int Cout, int act, int tilesT) {
   __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, DB, BF3>()];
   conv_dgrad_body<KS, S, WM, WN, MI, NI, KC, KG, DB, BF3>(smem, ptrs, B, Tin, Cin, Tout, Cout, act, tilesT, blockIdx.x,
@@ -1078,8 +1107,9 @@ __global__ __launch_bounds__(256 * KG) void conv_wgrad_kernel(
 // K=1 data gradient AND weight gradient of the same layer(s) in ONE launch: workgroups [0, nW) run the wgrad body
 // (token-split, atomics into dw / dbias), workgroups [nW, nW + nD) the dgrad body.  Both read the same dy; issued as
 // one grid they fill the chip together instead of leaving two under-filled launches with a drain between them.
+// (fp32, 1024 threads: the second launch bound keeps two workgroups per CU -- 64 VGPRs -- with the float4 g fragments)
 template <int WM, int WN, int MI, int NI, int KC, int KGD, bool BF3 = false>
-__global__ __launch_bounds__(64 * WM * WN * KGD) void conv_bwd_pair_k1_kernel(
+__global__ __launch_bounds__(64 * WM * WN * KGD, ((!BF3 && WM == 1 && WN == 4 && KGD == 4) ? 8 : 1)) void conv_bwd_pair_k1_kernel(
     DgradPtrs dp, WgradPtrs wp, int nW, int wgx, int wgy, int wgz, int dgx, int dgy, int mtiles, int B, int T, int Cin,
     int Cout, int act, int tilesT, int tilesPerClip, int tilesPerSplit) {
   constexpr int KG = WM * WN * KGD / 4;          // wgrad K-groups: same workgroup size (4 waves per wgrad K-group)
@@ -1499,7 +1529,7 @@ static int conv1d_dgrad_launch(const DgradPtrs& ptrs, int nprob, int B, int Tin,
     const int tilesT = cdiv(Tin, BM_);                                                                    \
     dim3 grid(B * tilesT, cdiv(Cin, BN_), nprob);                                                         \
     constexpr int RAd_ = (BM_ + KS_ - 2) / S_ + 2;                                                        \
-    constexpr bool DBOK_ = 2 * (RAd_ * (KC_ + 1) + KC_ * BN_ * KS_ + 8) * 4 <= 150 * 1024;                \
+    constexpr bool DBOK_ = 2 * (RAd_ * (KC_ + 4) + KC_ * BN_ * KS_ + 8) * 4 <= 150 * 1024;                \
     if constexpr ((KC_ / KG_) % 16 == 0) {                                                                \
       if (g_gemm_mode & 2) {                                                                              \
         hipLaunchKernelGGL((conv_dgrad_kernel<KS_, S_, WM_, WN_, MI_, NI_, KC_, KG_, false, true>), grid, \
