@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   static_assert(TT * TH * TW == BM, "patch must cover the M tile");
   constexpr int HH = TH + 2, HW = TW + 2;
   constexpr int HV = TT * HH * HW;               // haloed voxels of one stage
-  constexpr int LDA = KC + 1, LDB = KC + 1;
+  // VEC (exact fp32, KC a multiple of 8): rows padded by 4 floats, 16-byte staging stores, and a lane fetches four
+  // k-steps of an operand row with one ds_read_b128 (MFMA j of an 8-deep step contracts channels {cc + j, cc + 4 + j})
+  constexpr bool VEC = !BF3 && (KC % 8 == 0);
+  constexpr int LDA = VEC ? KC + 4 : KC + 1, LDB = LDA;
   constexpr int A4 = KC / 4;
   constexpr int NA = (HV * A4 + 255) / 256, NB = (9 * BN * A4 + 255) / 256;
   constexpr int AS = (HV * LDA + 3) / 4 * 4;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
   for (int mi = 0; mi < MI; ++mi) {
     const int m = (wm * MI + mi) * 32 + li;
     const int pt = m / (TH * TW), ph = (m / TW) % TH, pw = m % TW;
-    abase[mi] = BF3 ? ((pt * HH + ph) * HW + pw) : ((pt * HH + ph) * HW + pw) * LDA + lh;     // BF3: the patch ROW (swizzled per read)
+    abase[mi] = BF3 ? ((pt * HH + ph) * HW + pw) : ((pt * HH + ph) * HW + pw) * LDA + (VEC ? lh * 4 : lh);     // BF3: the patch ROW (swizzled per read)
   }
 
   F4Buf<NA> ra;
@@ -130,6 +133,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
           const int off = row * LDH + swz(row, c4 >> 1) * 8 + (c4 & 1) * 4;
           *reinterpret_cast<uint2*>(Ah + off) = hi;
           *reinterpret_cast<uint2*>(Al + off) = lo;
+        } else if (VEC) {
+          *reinterpret_cast<float4*>(As + (q / A4) * LDA + (q % A4) * 4) = ra.v[i];
         } else {
           float* d = As + (q / A4) * LDA + (q % A4) * 4;
           d[0] = ra.v[i].x; d[1] = ra.v[i].y; d[2] = ra.v[i].z; d[3] = ra.v[i].w;
@@ -147,6 +152,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
           const int off = row * LDH + swz(row, c4 >> 1) * 8 + (c4 & 1) * 4;
           *reinterpret_cast<uint2*>(Bh + off) = hi;
           *reinterpret_cast<uint2*>(Bl + off) = lo;
+        } else if (VEC) {
+          *reinterpret_cast<float4*>(Bs + (q / A4) * LDB + (q % A4) * 4) = rb.v[i];
         } else {
           float* d = Bs + (q / A4) * LDB + (q % A4) * 4;
           d[0] = rb.v[i].x; d[1] = rb.v[i].y; d[2] = rb.v[i].z; d[3] = rb.v[i].w;
@@ -191,6 +198,30 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(
               c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], c_, 0, 0, 0);
               acc[mi * NI + ni] = c_;
             }
+        }
+      }
+    } else if constexpr (VEC) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int aoff = ((tap / 3) * HW + (tap % 3)) * LDA;
+#pragma unroll
+        for (int cc = 0; cc < KC; cc += 8) {
+          float4 a4[MI], b4[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a4[mi] = *reinterpret_cast<const float4*>(As + abase[mi] + aoff + cc);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            b4[ni] = *reinterpret_cast<const float4*>(Bs + (tap * BN + (wn * NI + ni) * 32 + li) * LDB + cc + lh * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                const float av = j == 0 ? a4[mi].x : (j == 1 ? a4[mi].y : (j == 2 ? a4[mi].z : a4[mi].w));
+                const float bv = j == 0 ? b4[ni].x : (j == 1 ? b4[ni].y : (j == 2 ? b4[ni].z : b4[ni].w));
+                acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi * NI + ni], 0, 0, 0);
+              }
         }
       }
     } else {
