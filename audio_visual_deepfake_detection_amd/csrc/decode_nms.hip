@@ -30,9 +30,9 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
   __shared__ float s0[kMaxP], s1[kMaxP];        // segment of flat point p (feature-grid units)
   __shared__ unsigned char alive[kMaxP];
   __shared__ int kept[256];
-  __shared__ int n_cand, n_nms, n_keep;
+  __shared__ int n_cand, n_nms;
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) { n_cand = 0; n_nms = 0; n_keep = 0; }
+  if (tid == 0) { n_cand = 0; n_nms = 0; }
   __syncthreads();
 
   int lc = 0, ln = 0;
@@ -76,10 +76,13 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
   __syncthreads();
 
   // greedy NMS in rank order; only the first max_seg survivors are ever reported
+  // (the survivor count lives in a register of every thread -- alive[i] is read uniformly, so all threads count alike --
+  // and one barrier per kept segment orders the suppression writes before the next alive[] read)
   const int cap = max_seg < 256 ? max_seg : 256;
+  int nkeep = 0;
   for (int i = 0; i < nn; ++i) {
     if (!alive[i]) continue;                    // uniform: LDS value read after the last barrier
-    if (tid == 0) { kept[n_keep] = i; }
+    if (tid == 0) { kept[nkeep] = i; }
     const int pi = key[i].idx;
     const float ix1 = s0[pi], ix2 = s1[pi];
     const float ia = ix2 - ix1 + 1e-6f;
@@ -92,13 +95,11 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
       const float ovr = inter / (ia + ja - inter);
       if (ovr >= iou_thr) alive[j] = 0;
     }
+    if (++nkeep >= cap) break;
     __syncthreads();
-    if (tid == 0) n_keep = n_keep + 1;
-    __syncthreads();
-    if (n_keep >= cap) break;
   }
   __syncthreads();
-  const int nk = n_keep;
+  const int nk = nkeep;
   const int nc = n_cand;     // voting pool = every decoded candidate (ranks [0, nc)), nms.py:176-182
 
   const int lane = tid & 63, wid = tid >> 6;
@@ -109,20 +110,26 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
     if (voting_thr > 0.f) {
       const float la = a1 - a0;
       float wsum = 0.f;
-      for (int j = lane; j < nc; j += 64) {
-        const int pj = key[j].idx;
-        const float inter = fmaxf(fminf(a1, s1[pj]) - fmaxf(a0, s0[pj]), 0.f);
-        const float iou = inter / (la + (s1[pj] - s0[pj]) - inter);
-        if (iou >= voting_thr) wsum += key[j].score * iou;
+      float sw[kMaxP / 64];                      // score * iou of this lane's candidates (0 below the voting threshold)
+#pragma unroll
+      for (int m = 0; m < kMaxP / 64; ++m) {
+        const int j = lane + m * 64;
+        sw[m] = 0.f;
+        if (j < nc) {
+          const int pj = key[j].idx;
+          const float inter = fmaxf(fminf(a1, s1[pj]) - fmaxf(a0, s0[pj]), 0.f);
+          const float iou = inter / (la + (s1[pj] - s0[pj]) - inter);
+          if (iou >= voting_thr) { sw[m] = key[j].score * iou; wsum += sw[m]; }
+        }
       }
       wsum = wave_sum(wsum);
       float r0 = 0.f, r1 = 0.f;
-      for (int j = lane; j < nc; j += 64) {
-        const int pj = key[j].idx;
-        const float inter = fmaxf(fminf(a1, s1[pj]) - fmaxf(a0, s0[pj]), 0.f);
-        const float iou = inter / (la + (s1[pj] - s0[pj]) - inter);
-        if (iou >= voting_thr) {
-          const float wgt = key[j].score * iou / wsum;
+#pragma unroll
+      for (int m = 0; m < kMaxP / 64; ++m) {
+        const int j = lane + m * 64;
+        if (j < nc && sw[m] != 0.f) {
+          const int pj = key[j].idx;
+          const float wgt = sw[m] / wsum;
           r0 += wgt * s0[pj];
           r1 += wgt * s1[pj];
         }
