@@ -753,3 +753,24 @@ def test_local_attention_rel_pe_and_time_weight_match_reference(golden_dir):
     close(m.rel_pe.grad, torch.from_numpy(g["drel"]), "d rel_pe", rtol=1e-4)
     close(m.time_weighting.grad, torch.from_numpy(g["dtw"]), "d time_weighting", rtol=1e-4)
     close(m.query.weight.grad, torch.from_numpy(g["dqw"]), "d query.weight", rtol=1e-4)
+
+
+def test_tuned_extra_rows_swap_plans_at_run_time(ops):
+    """avdf_tuned_extra (tools/plan_search.py): plan rows set at run time are honoured for exactly their shape -- every
+    forward tile / K-group plan gives the float64 result -- and clearing them restores the table."""
+    import ctypes
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    B, T, Cin, Cout = 3, 64, 256, 256
+    x, w = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, 1, seed=2, scale=Cin ** -0.5)
+    ref = F.conv1d(x.transpose(1, 2), w).transpose(1, 2)
+    xd, wd = g32(x), g32(w)
+    try:
+        for tile, kg in [(0, 1), (1, 2), (2, 4), (3, 4), (5, 2), (6, 4)]:
+            row = f"0,1,1,{B * T},{Cout},{Cin},{tile},{kg}".encode()
+            check(lib.avdf_tuned_extra(ctypes.c_char_p(row)), "tuned_extra")
+            close(ops.conv1d(xd, wd), ref, f"forward with the run-time row ({tile},{kg})")
+        check(lib.avdf_tuned_extra(ctypes.c_char_p(b"not a row")), "tuned_extra")       # unparsable text = no rows
+        close(ops.conv1d(xd, wd), ref, "forward after a rejected row string")
+    finally:
+        check(lib.avdf_tuned_extra(None), "tuned_extra")
+    close(ops.conv1d(xd, wd), ref, "forward with the table restored")
