@@ -242,12 +242,6 @@ __global__ __launch_bounds__(64 * WM * WN * KG, (fwd_waves_per_simd<KS, S, WM, W
   constexpr int SM = cmax((DB ? 2 : 1) * TILE, KG * BM * (BN + 4));
   static_assert(SM == fwd_smem_floats<KS, S, WM, WN, MI, NI, KC, KG, BF3, DB>(), "smem size");
   __shared__ __attribute__((aligned(16))) float smem[SM];
-  float* As = smem;
-  float* Bs = smem + AS;
-  __bf16* Ah = reinterpret_cast<__bf16*>(smem);
-  __bf16* Al = Ah + ASH;
-  __bf16* Bh = Al + ASH;
-  __bf16* Bl = Bh + BSH;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kg = wid / WPG, w4 = wid % WPG;
