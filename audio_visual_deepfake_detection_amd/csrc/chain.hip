@@ -307,7 +307,7 @@ constexpr int kTile = 32, kWaves = 8;
 constexpr int kWavesB = 8;
 // tile sizes are host-side launch parameters (AVDF_CHAIN_TILE_F in {16, 32}, AVDF_CHAIN_TILE_B in {8, 16, 32}: in-situ A/B)
 static const int g_tile_f = [] { const char* e = getenv("AVDF_CHAIN_TILE_F"); const int v = e ? atoi(e) : kTile; return v == 16 ? 16 : 32; }();
-static const int g_tile_b = [] { const char* e = getenv("AVDF_CHAIN_TILE_B"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 32) ? v : 16; }();
+static const int g_tile_b = [] { const char* e = getenv("AVDF_CHAIN_TILE_B"); const int v = e ? atoi(e) : 16; return (v == 8 || v == 32 || v == 12) ? v : 16; }();
 
 }  // namespace
 
@@ -383,14 +383,17 @@ extern "C" int avdf_chain_bwd_res(const float* const* dy, const float* const* u,
   }
   hipStream_t st = (hipStream_t)stream;
   const int tiles = cdiv(Tin, g_tile_b);
-#define LAUNCH_CB(S_, TI_)                                                                                            \
+#define LAUNCH_CB2(S_, TI_, NW_)                                                                                     \
   do {                                                                                                                \
     constexpr int RU = TI_ / S_ + 2;                                                                                  \
-    hipLaunchKernelGGL((chain_bwd_kernel<S_, TI_, kWavesB>), dim3(B * tiles), dim3(64 * kWavesB),                     \
-                       (size_t)(RU + kWavesB * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask); \
+    hipLaunchKernelGGL((chain_bwd_kernel<S_, TI_, NW_>), dim3(B * tiles), dim3(64 * NW_),                             \
+                       (size_t)(RU + NW_ * 7) * C * sizeof(float), st, a, mask, ws, B, Tin, Tout, C, tiles, store_mask); \
   } while (0)
-  if (stride == 1) { if (g_tile_b == 8) LAUNCH_CB(1, 8); else if (g_tile_b == 32) LAUNCH_CB(1, 32); else LAUNCH_CB(1, 16); }
-  else { if (g_tile_b == 8) LAUNCH_CB(2, 8); else if (g_tile_b == 32) LAUNCH_CB(2, 32); else LAUNCH_CB(2, 16); }
+#define LAUNCH_CB(S_, TI_) LAUNCH_CB2(S_, TI_, kWavesB)
+  // (12-row tiles, 6 waves: 8 x 768 / 12 = 512 workgroups = exactly two per CU at the top pyramid level)
+  if (stride == 1) { if (g_tile_b == 8) LAUNCH_CB(1, 8); else if (g_tile_b == 32) LAUNCH_CB(1, 32); else if (g_tile_b == 12) LAUNCH_CB2(1, 12, 6); else LAUNCH_CB(1, 16); }
+  else { if (g_tile_b == 8) LAUNCH_CB(2, 8); else if (g_tile_b == 32) LAUNCH_CB(2, 32); else if (g_tile_b == 12) LAUNCH_CB2(2, 12, 6); else LAUNCH_CB(2, 16); }
+#undef LAUNCH_CB2
 #undef LAUNCH_CB
   AVDF_CHECK_LAUNCH("chain_bwd");
   return AVDF_OK;
