@@ -370,10 +370,12 @@ def test_adamw_ema_kernel(ops):
 # fused LN -> depthwise k3 -> LN chains of q / k / v
 @pytest.mark.parametrize("B,T,C,stride,share", [(2, 96, 256, 1, "all"), (3, 70, 64, 1, "kv"), (2, 64, 32, 2, "none"),
                                                 (8, 768, 256, 1, "all"), (2, 130, 256, 2, "kv"), (1, 33, 8, 1, "all")])
-@pytest.mark.parametrize("passthrough", [False, True])
-def test_qkv_chain_matches_torch(ops, B, T, C, stride, share, passthrough):
+@pytest.mark.parametrize("passthrough,main", [(False, False), (True, False), (True, True)])
+def test_qkv_chain_matches_torch(ops, B, T, C, stride, share, passthrough, main):
     """passthrough: the op also hands x_q back (4th output) for the block's residual connection; its gradient must be
-    summed into dx by the backward kernel (the reference graph simply uses x_q twice)."""
+    summed into dx by the backward kernel (the reference graph simply uses x_q twice).  main: the engine path -- every
+    parameter owns a `main_grad` buffer and the backward kernel ADDS its partial sums there (float atomics; branches that
+    share a parameter meet in its buffer), autograd sees no parameter gradient."""
     if stride == 2 and T % 2:
         T += 1
     Tout = (T - 1) // stride + 1
@@ -411,6 +413,13 @@ def test_qkv_chain_matches_torch(ops, B, T, C, stride, share, passthrough):
         if id(t) not in dmap:
             dmap[id(t)] = g32(t, True)
         return dmap[id(t)]
+    base = {}
+    if main:
+        for t in [a for pr in la for a in pr] + dw + [a for pr in lb for a in pr]:
+            d = dleaf(t)
+            if not hasattr(d, "main_grad"):
+                d.main_grad = g32(rnd(*t.shape, seed=90 + len(base)))          # accumulate ON TOP of existing contents
+                base[id(t)] = d.main_grad.clone()
     got = ops.qkv_chain([dleaf(x) for x in xs], [(dleaf(a), dleaf(b)) for a, b in la], [dleaf(w) for w in dw],
                         [(dleaf(a), dleaf(b)) for a, b in lb], g32(mask), stride, eps, passthrough=passthrough)
     assert len(got) == (4 if passthrough else 3)
@@ -422,7 +431,11 @@ def test_qkv_chain_matches_torch(ops, B, T, C, stride, share, passthrough):
         loss = loss + (got[3] * g32(dres)).sum()
     loss.backward()
     for key, t64 in uniq.items():
-        close(dmap[key].grad, t64.grad, f"chain grad of tensor shape {tuple(t64.shape)}", rtol=5e-5)
+        if key in base:
+            assert dmap[key].grad is None, "accumulate path must not hand a parameter gradient to autograd"
+            close(dmap[key].main_grad - base[key], t64.grad, f"chain main_grad of tensor shape {tuple(t64.shape)}", rtol=5e-5)
+        else:
+            close(dmap[key].grad, t64.grad, f"chain grad of tensor shape {tuple(t64.shape)}", rtol=5e-5)
 
 
 @pytest.mark.parametrize("B,T,C,bias,main", [(2, 96, 64, True, False), (8, 768, 256, True, True), (3, 50, 32, False, False)])
