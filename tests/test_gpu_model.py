@@ -150,7 +150,7 @@ def test_training_losses_and_gradients_match_reference_goldens(golden_dir, name,
         assert abs(float(losses["reco_seg_loss"]) - float(g["reco_seg_loss"])) < 1e-5
     if cfg["variant"] == "recon":
         assert abs(float(losses["reco_loss"]) - float(g["reco_loss"])) < 1e-5
-    got = np.array([float(losses[k]) if k in losses else 0.0 for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
+    got = np.array([float(losses[k].detach()) if k in losses else 0.0 for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
     print(f"[{name}] losses got {got} ref {g['losses']}")
     assert np.allclose(got, g["losses"], rtol=1e-4, atol=1e-5)
     assert abs(model.loss_normalizer - float(g["loss_normalizer"])) < 1e-3

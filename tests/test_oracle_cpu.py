@@ -73,7 +73,7 @@ def test_oracle_training_losses_and_gradients_match_reference(golden_dir, name, 
     out = R.model_forward(sd, cfg, x, mask, training=True)
     ol, norm, _ = R.losses(cfg, out, gts, gls, cfg["init_loss_norm"], x_in=x, gt_frame_labels=gfl if the else None)
     ol["final_loss"].backward()
-    got = np.array([float(ol[k]) if k in ol else 0.0 for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
+    got = np.array([float(ol[k].detach()) if k in ol else 0.0 for k in ("cls_loss", "reg_loss", "reco_cls_loss", "final_loss")])
     assert np.allclose(got, g["losses"], rtol=1e-4, atol=1e-6), (got, g["losses"])
     assert abs(norm - float(g["loss_normalizer"])) < 1e-4
     for key in g.files:
