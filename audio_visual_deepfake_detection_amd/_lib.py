@@ -35,6 +35,8 @@ SIGNATURES = {
     "avdf_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, I, P, P, I, P]),
     "avdf_layernorm_bwd_ws": (L, [I, I]),
     "avdf_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "avdf_layernorm_fwd_rs": (I, [P, P, P, P, P, P, I, I, F, I, P, P]),
+    "avdf_layernorm_bwd_rs": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "avdf_dwconv_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "avdf_dwconv_bwd_ws": (L, [I, I, I]),
     "avdf_dwconv_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),

@@ -18,7 +18,10 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-    int M, int C, float eps, int relu, const float* __restrict__ pe, const float* __restrict__ mask, int T) {
+    int M, int C, float eps, int relu, const float* __restrict__ pe, const float* __restrict__ mask, int T,
+    const float* __restrict__ rowscale) {
+  // rowscale (optional): y = act(LN(x)) * rowscale[row] -- the shared heads run on the gapped concatenation of the pyramid
+  // levels and put the gap rows back to zero after every LayerNorm (one launch less per layer than a separate row scale)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wid;
   if (row >= M) return;
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
   if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
   const float mk = (pe && mask) ? mask[row] : 1.0f;
+  const float rs = rowscale ? rowscale[row] : 1.0f;
   const int t = pe ? row % T : 0;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
         const float4 p = ld4(pe + (size_t)t * C + c);
         o.x += p.x * mk; o.y += p.y * mk; o.z += p.z * mk; o.w += p.w * mk;
       }
+      if (rowscale) { o.x *= rs; o.y *= rs; o.z *= rs; o.w *= rs; }
       *reinterpret_cast<float4*>(y + (size_t)row * C + c) = o;
     }
   }
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
     float* __restrict__ dx, float* __restrict__ ws, float* __restrict__ dg_atomic, float* __restrict__ db_atomic,
-    int M, int C, int relu) {
+    int M, int C, int relu, const float* __restrict__ rowscale) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [NW][2][C]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[NV], ab[NV];
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
   for (int j = 0; j < NV; ++j) { ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j]; }
   for (int row = blockIdx.x * NW + wid; row < M; row += gridDim.x * NW) {
     const float mean = mean_i[row], rstd = rstd_i[row];
+    const float rs = rowscale ? rowscale[row] : 1.0f;
     float4 xh[NV], gy[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
       if (c < C) {
         const float4 xv = ld4(x + (size_t)row * C + c);
         float4 d = ld4(dy + (size_t)row * C + c);
+        d.x *= rs; d.y *= rs; d.z *= rs; d.w *= rs;
         float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gamma) { g = ld4(gamma + c); bb = ld4(beta + c); }
         float4 h;
@@ -247,9 +254,27 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+static int layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              int M, int C, float eps, int relu, const float* pe, const float* mask, int T,
+                              const float* rowscale, void* stream);
+
 extern "C" int avdf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                                   float* mean, float* rstd, int M, int C, float eps, int relu,
                                   const float* pe, const float* mask, int T, void* stream) {
+  return layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, M, C, eps, relu, pe, mask, T, nullptr, stream);
+}
+
+// y = act(LN(x)) * rowscale[row] (no position table): the LayerNorms of the shared heads on the gapped level sequence
+extern "C" int avdf_layernorm_fwd_rs(const float* x, const float* gamma, const float* beta, float* y,
+                                     float* mean, float* rstd, int M, int C, float eps, int relu,
+                                     const float* rowscale, void* stream) {
+  AVDF_REQUIRE(rowscale, "layernorm_fwd_rs: null rowscale");
+  return layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, M, C, eps, relu, nullptr, nullptr, 0, rowscale, stream);
+}
+
+static int layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              int M, int C, float eps, int relu, const float* pe, const float* mask, int T,
+                              const float* rowscale, void* stream) {
   AVDF_REQUIRE(x && y && M > 0 && C > 0, "layernorm_fwd: bad args");
   AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "layernorm_fwd: C must be a multiple of 4 and <= %d (C=%d)", 256 * kLnMaxV, C);
   AVDF_REQUIRE((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta must both be given or both NULL");
@@ -257,7 +282,7 @@ extern "C" int avdf_layernorm_fwd(const float* x, const float* gamma, const floa
   AVDF_REQUIRE(!pe || T > 0, "layernorm_fwd: pe needs T");
   AVDF_REQUIRE(aligned16(x) && aligned16(y) && (!gamma || (aligned16(gamma) && aligned16(beta))) && (!pe || aligned16(pe)), "layernorm_fwd: 16-byte alignment");
 #define LN_FWD(NV_) hipLaunchKernelGGL(ln_fwd_kernel<NV_>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, \
-                                      x, gamma, beta, y, mean, rstd, M, C, eps, relu, pe, mask, T)
+                                      x, gamma, beta, y, mean, rstd, M, C, eps, relu, pe, mask, T, rowscale)
   if (C <= 256) LN_FWD(1); else if (C <= 512) LN_FWD(2); else if (C <= 1024) LN_FWD(4); else LN_FWD(8);
 #undef LN_FWD
   AVDF_CHECK_LAUNCH("layernorm_fwd");
@@ -405,9 +430,27 @@ static int ln_bwd_blocks(int M, int C) {
 
 extern "C" int64_t avdf_layernorm_bwd_ws(int M, int C) { return (int64_t)2 * ln_bwd_blocks(M, C) * C; }
 
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, int M, int C, int relu,
+                              int accumulate, const float* rowscale, void* stream);
+
 extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
                                   const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
                                   float* ws, int M, int C, int relu, int accumulate, void* stream) {
+  return layernorm_bwd_impl(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, ws, M, C, relu, accumulate, nullptr, stream);
+}
+
+// backward of avdf_layernorm_fwd_rs: the incoming gradient is scaled by rowscale[row] on load
+extern "C" int avdf_layernorm_bwd_rs(const float* dy, const float* x, const float* gamma, const float* beta,
+                                     const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                                     float* ws, int M, int C, int relu, int accumulate, const float* rowscale, void* stream) {
+  AVDF_REQUIRE(rowscale, "layernorm_bwd_rs: null rowscale");
+  return layernorm_bwd_impl(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, ws, M, C, relu, accumulate, rowscale, stream);
+}
+
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, int M, int C, int relu,
+                              int accumulate, const float* rowscale, void* stream) {
   AVDF_REQUIRE(dy && x && mean && rstd && dx && ws && M > 0 && C > 0, "layernorm_bwd: bad args");
   AVDF_REQUIRE(relu == 0 || relu == 1, "layernorm_bwd: only the none / ReLU epilogues have a backward");
   AVDF_REQUIRE(C % 4 == 0 && C <= 256 * kLnMaxV, "layernorm_bwd: C must be a multiple of 4 and <= %d", 256 * kLnMaxV);
@@ -420,7 +463,7 @@ extern "C" int avdf_layernorm_bwd(const float* dy, const float* x, const float* 
   float* dba = atomic ? dbeta : nullptr;
 #define LN_BWD(NV_, NW_) hipLaunchKernelGGL((ln_bwd_kernel<NV_, NW_>), dim3(G), dim3(64 * NW_),                 \
                                            (size_t)2 * NW_ * C * sizeof(float), st, dy, x, gamma, beta, mean, rstd, \
-                                           dx, ws, dga, dba, M, C, relu)
+                                           dx, ws, dga, dba, M, C, relu, rowscale)
   if (C <= 256) LN_BWD(1, 16); else if (C <= 512) LN_BWD(2, 8); else if (C <= 1024) LN_BWD(4, 4); else LN_BWD(8, 4);
 #undef LN_BWD
   AVDF_CHECK_LAUNCH("layernorm_bwd");

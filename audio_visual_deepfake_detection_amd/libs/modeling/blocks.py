@@ -111,9 +111,9 @@ class LayerNorm(nn.Module):
             self.register_parameter('weight', None)
             self.register_parameter('bias', None)
 
-    def forward(self, x, relu=False, pe=None, mask=None):
+    def forward(self, x, relu=False, pe=None, mask=None, rowscale=None):
         assert x.shape[-1] == self.num_channels
-        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, pe, mask)
+        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, pe, mask, rowscale)
 
 
 def get_sinusoid_encoding(n_position, d_hid):

@@ -77,7 +77,7 @@ class PtTransformerClsHead(nn.Module):
         cur = x
         for idx in range(len(self.head)):
             cur, _ = self.head[idx](cur, gmask)
-            cur = ops.scale_rows(self.norm[idx](cur, relu=True), keep)         # gap rows back to zero
+            cur = self.norm[idx](cur, relu=True, rowscale=keep)               # LN + ReLU, gap rows back to zero
         return ops.smallconv(cur, self.cls_head.conv.weight, self.cls_head.conv.bias, gmask)
 
     def forward(self, fpn_feats, fpn_masks):
@@ -107,7 +107,7 @@ class PtTransformerRegHead(nn.Module):
         cur = x
         for idx in range(len(self.head)):
             cur, _ = self.head[idx](cur, gmask)
-            cur = ops.scale_rows(self.norm[idx](cur, relu=True), keep)
+            cur = self.norm[idx](cur, relu=True, rowscale=keep)
         y = ops.smallconv(cur, self.offset_head.conv.weight, self.offset_head.conv.bias, gmask)
         # per-level Scale then ReLU (av_fd_no_recon.py:155-156) fused into the compaction to point order [B, P, 2]
         return ops.head_out(y, lens, relu=True, scales=[self.scale[l].scale for l in range(len(lens))])

@@ -574,7 +574,7 @@ def view_param(p, shape):
 # --------------------------------------------------------------------------------------------
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, pe, mask):
+    def forward(ctx, x, gamma, beta, eps, relu, pe, mask, rowscale=None):
         x = _c(x)
         shp = x.shape
         C = shp[-1]
@@ -586,8 +586,17 @@ class LayerNormFn(torch.autograd.Function):
         T = shp[-2] if pe is not None else 0
         g = None if gamma is None else gamma.contiguous().view(-1)
         b = None if beta is None else beta.contiguous().view(-1)
-        check(lib.avdf_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, C, eps, int(relu),
-                                     _p(_c(pe)), _p(_c(mask)), T, _stream()), "layernorm_fwd")
+        rs = None
+        if rowscale is not None:
+            # y = act(LN(x)) * rowscale[row]: the heads zero the gap rows of the concatenated level sequence in the LN launch
+            assert pe is None and mask is None and rowscale.numel() == M
+            rs = rowscale.contiguous().view(-1)
+            check(lib.avdf_layernorm_fwd_rs(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, C, eps, int(relu), _p(rs),
+                                            _stream()), "layernorm_fwd_rs")
+        else:
+            check(lib.avdf_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), M, C, eps, int(relu),
+                                         _p(_c(pe)), _p(_c(mask)), T, _stream()), "layernorm_fwd")
+        ctx.rs = rs
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.cfg = (M, C, int(relu), None if gamma is None else gamma.shape)
         ctx.main = (_main_grad(gamma), _main_grad(beta))
@@ -606,17 +615,21 @@ class LayerNormFn(torch.autograd.Function):
             dg = mg.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
             db = mb.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
         ws = _ws(lib.avdf_layernorm_bwd_ws(M, C), x)
-        check(lib.avdf_layernorm_bwd(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
-                                     M, C, relu, acc, _stream()), "layernorm_bwd")
+        if ctx.rs is not None:
+            check(lib.avdf_layernorm_bwd_rs(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
+                                            M, C, relu, acc, _p(ctx.rs), _stream()), "layernorm_bwd_rs")
+        else:
+            check(lib.avdf_layernorm_bwd(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
+                                         M, C, relu, acc, _stream()), "layernorm_bwd")
         if acc:
             dg = db = None
         elif dg is not None:
             dg, db = dg.view(gshape), db.view(gshape)
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, relu=False, pe=None, mask=None):
-    return LayerNormFn.apply(x, gamma, beta, eps, relu, pe, mask)
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, pe=None, mask=None, rowscale=None):
+    return LayerNormFn.apply(x, gamma, beta, eps, relu, pe, mask, rowscale)
 
 
 # --------------------------------------------------------------------------------------------

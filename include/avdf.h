@@ -132,6 +132,14 @@ int64_t avdf_layernorm_bwd_ws(int M, int C);
 int avdf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
                        float* ws, int M, int C, int relu, int accumulate, void* stream);
+/* LayerNorm with a row scale folded in: y = act(LN(x)) * rowscale[row] (forward) and dy * rowscale[row] on load
+ * (backward).  The shared classification / regression heads run on the gapped concatenation of the pyramid levels and
+ * zero the gap rows after every LayerNorm (av_fd_no_recon.py:78-85,145-152 applied level by level in the reference). */
+int avdf_layernorm_fwd_rs(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          int M, int C, float eps, int relu, const float* rowscale, void* stream);
+int avdf_layernorm_bwd_rs(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                          const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, int M, int C, int relu,
+                          int accumulate, const float* rowscale, void* stream);
 
 /* ---- depthwise conv k3 (+mask) -- query/key/value_conv (blocks.py:934-952) and fpn_convs
  * (necks.py:48-51): y[b,t,c] = (sum_k x[b,t*stride+k-1,c]*w[c,0,k]) * mask[b,t]            */

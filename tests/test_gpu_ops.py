@@ -119,6 +119,30 @@ def test_layernorm(ops, C, relu, use_pe):
     close(bg.grad, br.grad, "ln dbeta")
 
 
+@pytest.mark.parametrize("C,relu", [(256, True), (32, False), (516, True)])
+def test_layernorm_with_row_scale(ops, C, relu):
+    """y = act(LN(x)) * rowscale[row] in ONE launch (the heads' LayerNorms on the gapped level sequence), forward and
+    backward, against the composition of the plain ops in float64."""
+    B, T = 3, 50
+    x = rnd(B, T, C, seed=5, scale=2.0) + 0.5
+    g, b = rnd(1, C, 1, seed=6) * 0.2 + 1.0, rnd(1, C, 1, seed=7) * 0.2
+    rs = (torch.rand(B, T, generator=torch.Generator().manual_seed(3)) > 0.3).double() * (1.0 + 0.5 * rnd(B, T, seed=4).abs())
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (C,), gr.view(-1), br.view(-1), 1e-5)
+    if relu:
+        y = F.relu(y)
+    y = y * rs[:, :, None]
+    gy = rnd(B, T, C, seed=9)
+    y.backward(gy)
+    xg, gg, bg = g32(x, True), g32(g, True), g32(b, True)
+    yo = ops.layernorm(xg, gg, bg, 1e-5, relu, None, None, g32(rs))
+    close(yo, y, "ln*rowscale fwd")
+    yo.backward(g32(gy))
+    close(xg.grad, xr.grad, "ln*rowscale dx")
+    close(gg.grad, gr.grad, "ln*rowscale dgamma")
+    close(bg.grad, br.grad, "ln*rowscale dbeta")
+
+
 @pytest.mark.parametrize("stride,C,T", [(1, 32, 96), (2, 256, 100), (1, 260, 10)])
 def test_dwconv(ops, stride, C, T):
     B = 3
