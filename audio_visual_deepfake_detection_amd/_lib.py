@@ -98,10 +98,12 @@ SIGNATURES = {
     "avdf_residual_ln_bwd_ws": (L, [I, I, I]),
     "avdf_residual_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "avdf_chain_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "avdf_chain_fwd_map": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "avdf_chain_bwd_ws": (L, [I, I, I]),
     "avdf_chain_bwd_rows": (I, [I, I]),
     "avdf_chain_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "avdf_chain_bwd_res": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
+    "avdf_chain_bwd_map": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, P]),
     "avdf_reduce_segments": (I, [P, I, I, I, P, P, P, P, I, P]),
     "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "avdf_conv3d_mode": (I, [I]),

@@ -40,7 +40,13 @@ __device__ __forceinline__ void load_taps(const float* __restrict__ w, int c, fl
 struct ChainFwdArgs {
   const float* x[3]; const float* ga[3]; const float* ba[3]; const float* w[3]; const float* gb[3]; const float* bb[3];
   float* u[3]; float* y[3]; float* sa[3]; float* sb[3];
+  // optional nearest resampling of a branch's INPUT, folded into the row address: xsh > 0: row t reads source row t >> xsh
+  // (F.interpolate nearest, scale 2^xsh); xsh < 0: row t reads source row t << -xsh (stride-2^-xsh subsampling); xT = rows
+  // per clip of the source.  Replaces the separate up/down-sampling launch in front of the k / v chains of the
+  // cross-level blocks (backbones.py:487-490) and the resampled copy of the tensor.
+  int xsh[3]; int xT[3];
 };
+__device__ __forceinline__ int map_row(int t, int sh) { return sh > 0 ? (t >> sh) : (sh < 0 ? (t << (-sh)) : t); }
 
 // grid (B * tiles, 3); TO output tokens per workgroup, NW waves
 template <int S, int TO, int NW>
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(64 * NW) void chain_fwd_kernel(ChainFwdArgs a, cons
       float4 z = f4(0.f);
       if (t >= 0 && t < Tin) {
         const size_t row = (size_t)b * Tin + t;
-        const float4 v = act ? ld4(x + row * C + c) : f4(0.f);
+        const size_t xrow = (size_t)b * a.xT[br] + map_row(t, a.xsh[br]);
+        const float4 v = act ? ld4(x + xrow * C + c) : f4(0.f);
         const float mean = wave_sum(hsum4(v)) * invC;
         const float4 d = act ? sub4(v, f4(mean)) : f4(0.f);
         const float rstd = 1.0f / sqrtf(wave_sum(hsum4(mul4(d, d))) * invC + eps);
@@ -116,6 +123,7 @@ struct ChainBwdArgs {
   const float* ga[3]; const float* ba[3]; const float* w[3]; const float* gb[3];
   float* dx[3];
   const float* dres[3];   // optional: gradient arriving at the same input through the residual path, added into dx
+  int xsh[3]; int xT[3];  // input row map of the forward pass (see ChainFwdArgs); dx stays at the chain's own resolution
 };
 
 // ws row of a workgroup: [3 branches][7*C]: dgamma_a, dbeta_a, dw (c*3+k order, 3C), dgamma_b, dbeta_b
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(64 * NW) void chain_bwd_kernel(ChainBwdArgs a, cons
         xv[i] = f4(0.f); mn[i] = 0.f; rs[i] = 0.f;
         if (t < Tin) {
           const size_t row = (size_t)b * Tin + t;
-          if (act) xv[i] = ld4(a.x[br] + row * C + c);
+          if (act) xv[i] = ld4(a.x[br] + ((size_t)b * a.xT[br] + map_row(t, a.xsh[br])) * C + c);
           mn[i] = a.sa[br][row]; rs[i] = a.sa[br][BTi + row];
         }
       }
@@ -311,11 +319,49 @@ static const int g_tile_b = [] { const char* e = getenv("AVDF_CHAIN_TILE_B"); co
 
 }  // namespace
 
+static int set_row_map(const char* who, const int* xshift, int Tin, int (&xsh)[3], int (&xT)[3]) {
+  for (int i = 0; i < 3; ++i) {
+    const int sh = xshift ? xshift[i] : 0;
+    AVDF_REQUIRE(sh >= -6 && sh <= 6, "%s: input shift %d out of range", who, sh);
+    AVDF_REQUIRE(sh <= 0 || Tin % (1 << sh) == 0, "%s: Tin=%d is not a multiple of the up-sampling factor %d", who, Tin, 1 << sh);
+    xsh[i] = sh;
+    xT[i] = sh > 0 ? (Tin >> sh) : (sh < 0 ? (Tin << (-sh)) : Tin);
+  }
+  return AVDF_OK;
+}
+
+static int chain_fwd_impl(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                          const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                          const float* mask, float* const* u, float* const* y, float* const* stats_a,
+                          float* const* stats_b, const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps,
+                          void* stream);
+
 extern "C" int avdf_chain_fwd(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
                               const float* const* w, const float* const* gamma_b, const float* const* beta_b,
                               const float* mask, float* const* u, float* const* y, float* const* stats_a,
                               float* const* stats_b, int B, int Tin, int Tout, int C, int stride, float eps,
                               void* stream) {
+  return chain_fwd_impl(x, gamma_a, beta_a, w, gamma_b, beta_b, mask, u, y, stats_a, stats_b, nullptr, B, Tin, Tout, C, stride,
+                        eps, stream);
+}
+
+// avdf_chain_fwd with a nearest resampling of each branch's input folded into the row address: xshift[i] > 0: branch i reads
+// x[i] ([B, Tin >> s, C]) as if it were up-sampled by 2^s; < 0: reads every 2^-s-th row of x[i] ([B, Tin << -s, C]); 0: as is.
+extern "C" int avdf_chain_fwd_map(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                                  const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                                  const float* mask, float* const* u, float* const* y, float* const* stats_a,
+                                  float* const* stats_b, const int* xshift, int B, int Tin, int Tout, int C, int stride,
+                                  float eps, void* stream) {
+  AVDF_REQUIRE(xshift, "chain_fwd_map: null shift table");
+  return chain_fwd_impl(x, gamma_a, beta_a, w, gamma_b, beta_b, mask, u, y, stats_a, stats_b, xshift, B, Tin, Tout, C, stride,
+                        eps, stream);
+}
+
+static int chain_fwd_impl(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                          const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                          const float* mask, float* const* u, float* const* y, float* const* stats_a,
+                          float* const* stats_b, const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps,
+                          void* stream) {
   AVDF_REQUIRE(x && w && u && y && stats_a && stats_b && gamma_a && beta_a && gamma_b && beta_b, "chain_fwd: null table");
   AVDF_REQUIRE(B > 0 && Tin > 0 && C > 0 && C % 4 == 0 && C <= 256, "chain_fwd: C must be a multiple of 4, <= 256 (%d)", C);
   AVDF_REQUIRE(stride == 1 || stride == 2, "chain_fwd: stride must be 1 or 2");
@@ -331,6 +377,7 @@ extern "C" int avdf_chain_fwd(const float* const* x, const float* const* gamma_a
     a.x[i] = x[i]; a.ga[i] = gamma_a[i]; a.ba[i] = beta_a[i]; a.w[i] = w[i]; a.gb[i] = gamma_b[i]; a.bb[i] = beta_b[i];
     a.u[i] = u[i]; a.y[i] = y[i]; a.sa[i] = stats_a[i]; a.sb[i] = stats_b[i];
   }
+  { const int rc = set_row_map("chain_fwd", xshift, Tin, a.xsh, a.xT); if (rc) return rc; }
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_CF(S_, TO_)                                                                                          \
   do {                                                                                                              \
@@ -359,11 +406,38 @@ extern "C" int avdf_chain_bwd(const float* const* dy, const float* const* u, con
 
 // dres[i] (table or entries may be NULL): [B,Tin,C] gradient that reaches the input closed by branch i through another
 // path (the block's residual connection); dx[i] = LN_a backward sum + dres[i], saving autograd's separate add kernel.
+static int chain_bwd_impl(const float* const* dy, const float* const* u, const float* const* stats_b,
+                          const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                          const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                          const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
+                          const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream);
+
 extern "C" int avdf_chain_bwd_res(const float* const* dy, const float* const* u, const float* const* stats_b,
                                   const float* const* x, const float* const* stats_a, const float* const* gamma_a,
                                   const float* const* beta_a, const float* const* w, const float* const* gamma_b,
                                   const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
                                   int B, int Tin, int Tout, int C, int stride, void* stream) {
+  return chain_bwd_impl(dy, u, stats_b, x, stats_a, gamma_a, beta_a, w, gamma_b, mask, dx, dres, store_mask, ws, nullptr, B, Tin,
+                        Tout, C, stride, stream);
+}
+
+// backward of avdf_chain_fwd_map: x[i] is the un-resampled source, dx[i] is the gradient at the CHAIN's resolution
+// ([B, Tin, C]); the caller folds it back to the source rows (avdf_upsample_bwd / avdf_downsample_bwd)
+extern "C" int avdf_chain_bwd_map(const float* const* dy, const float* const* u, const float* const* stats_b,
+                                  const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                                  const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                                  const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
+                                  const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream) {
+  AVDF_REQUIRE(xshift, "chain_bwd_map: null shift table");
+  return chain_bwd_impl(dy, u, stats_b, x, stats_a, gamma_a, beta_a, w, gamma_b, mask, dx, dres, store_mask, ws, xshift, B, Tin,
+                        Tout, C, stride, stream);
+}
+
+static int chain_bwd_impl(const float* const* dy, const float* const* u, const float* const* stats_b,
+                          const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                          const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                          const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
+                          const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream) {
   AVDF_REQUIRE(dy && u && stats_b && x && stats_a && gamma_a && beta_a && w && gamma_b && dx && ws, "chain_bwd: null table");
   AVDF_REQUIRE(B > 0 && Tin > 0 && C > 0 && C % 4 == 0 && C <= 256, "chain_bwd: C must be a multiple of 4, <= 256 (%d)", C);
   AVDF_REQUIRE(stride == 1 || stride == 2, "chain_bwd: stride must be 1 or 2");
@@ -381,6 +455,7 @@ extern "C" int avdf_chain_bwd_res(const float* const* dy, const float* const* u,
     a.dres[i] = dres ? dres[i] : nullptr;
     AVDF_REQUIRE(aligned16(a.dres[i]) && (!a.dres[i] || ((store_mask >> i) & 1)), "chain_bwd: dres must be 16-byte aligned and belong to a closing branch");
   }
+  { const int rc = set_row_map("chain_bwd", xshift, Tin, a.xsh, a.xT); if (rc) return rc; }
   hipStream_t st = (hipStream_t)stream;
   const int tiles = cdiv(Tin, g_tile_b);
 #define LAUNCH_CB2(S_, TI_, NW_)                                                                                     \

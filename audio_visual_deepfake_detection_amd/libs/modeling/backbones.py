@@ -97,13 +97,23 @@ class ConvHRLRFullResSelfAttTransformerBackboneRevised(nn.Module):
         for idx in range(n):
             x, mask = self.branch[idx](x, mask)
             r = self.scale_factor ** (idx + 1)
-            up = ops.upsample(x, r)                                        # F.interpolate nearest (backbones.py:487)
-            lh_feat, lh_mask = self.lh_branch[idx](lh_feat, lh_mask, x_k=up, mask_k=lh_mask, x_v=up, mask_v=lh_mask)
+            if self.scale_factor == 2:
+                # the nearest up / down-sampling of the reference (backbones.py:487,490) is a row map inside the k / v chain
+                # kernels of the cross-level blocks: the resampled tensor is never materialised
+                lh_feat, lh_mask = self.lh_branch[idx](lh_feat, lh_mask, x_k=x, mask_k=lh_mask, x_v=x, mask_v=lh_mask,
+                                                       kv_shift=idx + 1)
+            else:
+                up = ops.upsample(x, r)                                    # F.interpolate nearest (backbones.py:487)
+                lh_feat, lh_mask = self.lh_branch[idx](lh_feat, lh_mask, x_k=up, mask_k=lh_mask, x_v=up, mask_v=lh_mask)
             out_feats.append(x)
             out_masks.append(mask)
             if idx < n - 1:
-                dn = ops.downsample(lh_feat, r)                            # backbones.py:490
-                x, mask = self.hh_branch[idx](x, mask, x_k=dn, mask_k=mask, x_v=dn, mask_v=mask)
+                if self.scale_factor == 2:
+                    x, mask = self.hh_branch[idx](x, mask, x_k=lh_feat, mask_k=mask, x_v=lh_feat, mask_v=mask,
+                                                  kv_shift=-(idx + 1))
+                else:
+                    dn = ops.downsample(lh_feat, r)                        # backbones.py:490
+                    x, mask = self.hh_branch[idx](x, mask, x_k=dn, mask_k=mask, x_v=dn, mask_v=mask)
         out_feats[0], out_masks[0] = lh_feat, lh_mask
         return out_feats, out_masks
 

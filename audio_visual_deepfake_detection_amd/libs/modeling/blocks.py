@@ -221,15 +221,28 @@ class _MHCABase(nn.Module):
         y, out_mask = conv(x, mask)
         return ops.conv1d(norm(y), proj.weight, proj.bias), out_mask
 
-    def attend_prenorm(self, xs, lns, masks):
+    def attend_prenorm(self, xs, lns, masks, kv_shift=0):
         """Block entry: pre-LayerNorms `lns` (ln1 x3 | lnq, lnk, lnv) + attention on raw inputs `xs`.  When the
         three branches share length and mask (every call site of the shipped backbones) the LN -> depthwise conv
-        -> LN chains of q, k, v run as ONE fused launch (ops.qkv_chain); otherwise the per-op path."""
+        -> LN chains of q, k, v run as ONE fused launch (ops.qkv_chain); otherwise the per-op path.
+        kv_shift != 0: x_k / x_v are given at THEIR pyramid level and stand for their nearest resampling to x_q's length
+        (> 0: up by 2^s, < 0: every 2^-s-th row -- backbones.py:487-490); the fused launch reads them through a row map,
+        the per-op path resamples them first."""
         x_q, x_k, x_v = xs
         C = x_q.shape[-1]
+        if kv_shift:
+            Tq = x_q.shape[1]
+            Tsrc = (Tq >> kv_shift) if kv_shift > 0 else (Tq << -kv_shift)
+            fusable = (ops.FUSE_QKV_CHAIN and C <= 256 and x_k is x_v and x_k.shape == (x_q.shape[0], Tsrc, C)
+                       and (kv_shift < 0 or Tq % (1 << kv_shift) == 0))
+            if not fusable:
+                r = 1 << abs(kv_shift)
+                x_k = ops.upsample(x_k, r) if kv_shift > 0 else ops.downsample(x_k, r)
+                x_v = x_k if xs[2] is xs[1] else (ops.upsample(x_v, r) if kv_shift > 0 else ops.downsample(x_v, r))
+                xs, kv_shift = (x_q, x_k, x_v), 0
         same_mask = all(m is masks[0] or (m.data_ptr() == masks[0].data_ptr() and m.shape == masks[0].shape)
                         for m in masks[1:])
-        if (ops.FUSE_QKV_CHAIN and C <= 256 and x_k.shape == x_q.shape and x_v.shape == x_q.shape and same_mask
+        if (ops.FUSE_QKV_CHAIN and C <= 256 and (kv_shift or (x_k.shape == x_q.shape and x_v.shape == x_q.shape)) and same_mask
                 and all(ln.affine for ln in lns) and len({ln.eps for ln in lns}) == 1
                 and self.query_norm.eps == lns[0].eps and x_q.shape[1] % self.n_kv_stride == 0):
             out_mask = downsample_mask(masks[0], self.n_kv_stride)
@@ -238,11 +251,16 @@ class _MHCABase(nn.Module):
             ys = ops.qkv_chain(
                 xs, [(ln.weight, ln.bias) for ln in lns],
                 [self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight],
-                [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps, passthrough=pt)
+                [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps, passthrough=pt,
+                xshift=(0, kv_shift, kv_shift) if kv_shift else None)
             q, k, v = ops.conv1d_group3(ys[:3], (self.query.weight, self.key.weight, self.value.weight),
                                         (self.query.bias, self.key.bias, self.value.bias))
             # ys[3] (training): x_q handed back by the chain op for the caller's residual connection
             return (*self._core(q, k, v, out_mask, out_mask), ys[3] if pt else x_q)
+        if kv_shift:                      # fused launch not applicable after all (masks / LayerNorm variants): resample first
+            r = 1 << abs(kv_shift)
+            x_k = ops.upsample(x_k, r) if kv_shift > 0 else ops.downsample(x_k, r)
+            x_v = x_k
         return (*self._attend(lns[0](x_q), masks[0], lns[1](x_k), masks[1], lns[2](x_v), masks[2]), x_q)
 
     def _core(self, q, k, v, qx_mask, kv_mask):
@@ -409,10 +427,10 @@ class MutilModelTransformerBlock(_BlockBase):
                                     attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop)
         self._build_common(n_embd, n_head, n_ds_strides, n_out, n_hidden, proj_pdrop, path_pdrop)
 
-    def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None, pos_embd=None):
+    def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None, pos_embd=None, kv_shift=0):
         assert pos_embd is None
         out, out_mask, x_res = self.attn.attend_prenorm((x_q, x_k, x_v), (self.lnq, self.lnk, self.lnv),
-                                                        (mask_q, mask_k, mask_v))
+                                                        (mask_q, mask_k, mask_v), kv_shift)
         return self._residual_mlp(x_res, out, out_mask), out_mask
 
 

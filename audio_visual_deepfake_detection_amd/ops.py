@@ -641,7 +641,10 @@ class QkvChainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xk, xv, gaq, baq, gak, bak, gav, bav, wq, wk, wv, gbq, bbq, gbk, bbk, gbv, bbv, mask, stride,
-                eps, passthrough=False):
+                eps, passthrough=False, xshift=None):
+        # xshift (optional, per branch): nearest resampling of that branch's input folded into the kernels' row address
+        # (> 0: the input has Tin >> s rows and is read as if up-sampled by 2^s; < 0: Tin << -s rows, every 2^-s-th read)
+        xshift = tuple(int(v) for v in (xshift or (0, 0, 0)))
         xs = [_c(xq), _c(xk), _c(xv)]
         ga, ba = [gaq, gak, gav], [baq, bak, bav]
         ws_, gb, bb = [wq, wk, wv], [gbq, gbk, gbv], [bbq, bbk, bbv]
@@ -651,7 +654,9 @@ class QkvChainFn(torch.autograd.Function):
         ga, ba, ws_, gb, bb = flat(ga), flat(ba), flat(ws_), flat(gb), flat(bb)
         mask = _c(mask)
         B, Tin, C = xs[0].shape
-        assert xs[1].shape == xs[0].shape and xs[2].shape == xs[0].shape
+        assert xshift[0] == 0, "the query branch defines the chain's resolution"
+        for xi, sh in zip(xs, xshift):
+            assert xi.shape == (B, (Tin >> sh) if sh > 0 else (Tin << -sh), C), (xi.shape, (B, Tin, C), sh)
         Tout = (Tin - 1) // stride + 1
         dev = xs[0].device
         u = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
@@ -660,12 +665,20 @@ class QkvChainFn(torch.autograd.Function):
         sb = torch.empty((3, 2, B * Tout), dtype=torch.float32, device=dev)
         for t in xs + ga + ba + ws_ + gb + bb:
             _p(t)
-        check(lib.avdf_chain_fwd(_ptr_table(xs), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_), _ptr_table(gb),
-                                 _ptr_table(bb), _p(mask), _ptr_table(u), _ptr_table(y), _ptr_table([sa[0], sa[1], sa[2]]),
-                                 _ptr_table([sb[0], sb[1], sb[2]]), B, Tin, Tout, C, stride, eps, _stream()), "chain_fwd")
+        if any(xshift):
+            check(lib.avdf_chain_fwd_map(_ptr_table(xs), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_), _ptr_table(gb),
+                                         _ptr_table(bb), _p(mask), _ptr_table(u), _ptr_table(y),
+                                         _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table([sb[0], sb[1], sb[2]]),
+                                         (ctypes.c_int * 3)(*xshift), B, Tin, Tout, C, stride, eps, _stream()), "chain_fwd_map")
+        else:
+            check(lib.avdf_chain_fwd(_ptr_table(xs), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_), _ptr_table(gb),
+                                     _ptr_table(bb), _p(mask), _ptr_table(u), _ptr_table(y), _ptr_table([sa[0], sa[1], sa[2]]),
+                                     _ptr_table([sb[0], sb[1], sb[2]]), B, Tin, Tout, C, stride, eps, _stream()), "chain_fwd")
         ctx.save_for_backward(*xs, *ga, *ba, *ws_, *gb, mask, *u, sa, sb)
         ctx.cfg = (B, Tin, Tout, C, stride)
+        ctx.xshift = xshift
         ctx.x_same = [xs[i + 1].data_ptr() == xs[i].data_ptr() for i in range(2)]
+        assert all(xshift[i] == xshift[i + 1] for i in range(2) if ctx.x_same[i]), "one input, two different row maps"
         ctx.passthrough = bool(passthrough)
         if ctx.passthrough:
             # 4th output = x_q itself: the caller uses it for the block's residual connection, so x_q has ONE consumer
@@ -691,10 +704,27 @@ class QkvChainFn(torch.autograd.Function):
         if dres is not None:
             # the branch that closes x_q's input group stores dx for it
             res[2 if (ctx.x_same[0] and ctx.x_same[1]) else (1 if ctx.x_same[0] else 0)] = dres.contiguous()
-        check(lib.avdf_chain_bwd_res(_ptr_table(dys), _ptr_table(u), _ptr_table([sb[0], sb[1], sb[2]]), _ptr_table(xs),
-                                     _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_),
-                                     _ptr_table(gb), _p(mask), _ptr_table(dx), _ptr_table(res), store_mask, _p(wsb), B, Tin,
-                                     Tout, C, stride, _stream()), "chain_bwd")
+        if any(ctx.xshift):
+            check(lib.avdf_chain_bwd_map(_ptr_table(dys), _ptr_table(u), _ptr_table([sb[0], sb[1], sb[2]]), _ptr_table(xs),
+                                         _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_),
+                                         _ptr_table(gb), _p(mask), _ptr_table(dx), _ptr_table(res), store_mask, _p(wsb),
+                                         (ctypes.c_int * 3)(*ctx.xshift), B, Tin, Tout, C, stride, _stream()), "chain_bwd_map")
+            # dx of a resampled input is at the chain's resolution: fold it back to the source rows (the backward of the
+            # nearest up / down-sampling that the forward skipped)
+            for i, sh in enumerate(ctx.xshift):
+                if sh == 0 or dx[i] is None:
+                    continue
+                src = torch.empty_like(xs[i])
+                if sh > 0:
+                    check(lib.avdf_upsample_bwd(_p(dx[i]), _p(src), B, Tin >> sh, C, 1 << sh, _stream()), "upsample_bwd")
+                else:
+                    check(lib.avdf_downsample_bwd(_p(dx[i]), _p(src), B, Tin << -sh, C, 1 << -sh, _stream()), "downsample_bwd")
+                dx[i] = src
+        else:
+            check(lib.avdf_chain_bwd_res(_ptr_table(dys), _ptr_table(u), _ptr_table([sb[0], sb[1], sb[2]]), _ptr_table(xs),
+                                         _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_),
+                                         _ptr_table(gb), _p(mask), _ptr_table(dx), _ptr_table(res), store_mask, _p(wsb), B, Tin,
+                                         Tout, C, stride, _stream()), "chain_bwd")
         # parameter gradients: one segmented reduction over the workgroups' rows; sources of a parameter shared by
         # several branches are summed there
         mains = ctx.main
@@ -728,16 +758,16 @@ class QkvChainFn(torch.autograd.Function):
                                        offs, 1 if acc else 0, _stream()), "reduce_segments")
         g = grads
         return (dx[0], dx[1], dx[2], g[0][0], g[1][0], g[0][1], g[1][1], g[0][2], g[1][2], g[2][0], g[2][1], g[2][2],
-                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None, None)
+                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None, None, None)
 
 
-def qkv_chain(xs, ln_a, dw, ln_b, mask_out, stride, eps=1e-5, passthrough=False):
+def qkv_chain(xs, ln_a, dw, ln_b, mask_out, stride, eps=1e-5, passthrough=False, xshift=None):
     """xs: 3 inputs [B,T,C]; ln_a / ln_b: 3 (gamma, beta) pairs; dw: 3 depthwise weights [C,1,3] -> 3 outputs
     (+ xs[0] handed back as a 4th output when `passthrough`: use THAT tensor for the residual connection and the
     gradient of the residual path is summed inside the chain's backward kernel instead of by a separate add)."""
     return QkvChainFn.apply(xs[0], xs[1], xs[2], ln_a[0][0], ln_a[0][1], ln_a[1][0], ln_a[1][1], ln_a[2][0], ln_a[2][1],
                             dw[0], dw[1], dw[2], ln_b[0][0], ln_b[0][1], ln_b[1][0], ln_b[1][1], ln_b[2][0], ln_b[2][1],
-                            mask_out, stride, eps, passthrough)
+                            mask_out, stride, eps, passthrough, xshift)
 
 
 # --------------------------------------------------------------------------------------------

@@ -386,6 +386,21 @@ int avdf_chain_bwd_res(const float* const* dy, const float* const* u, const floa
                        const float* const* beta_a, const float* const* w, const float* const* gamma_b,
                        const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
                        int B, int Tin, int Tout, int C, int stride, void* stream);
+/* avdf_chain_fwd / avdf_chain_bwd_res with a nearest resampling of each branch's INPUT folded into the row address (the
+ * up/down-sampling in front of the k / v chains of the cross-level blocks, backbones.py:487-490): xshift[i] > 0: x[i] is
+ * [B, Tin >> s, C] and row t reads source row t >> s; xshift[i] < 0: x[i] is [B, Tin << -s, C] and row t reads source row
+ * t << -s; 0: as is.  The backward returns dx[i] at the chain's resolution [B, Tin, C]; fold it back with
+ * avdf_upsample_bwd / avdf_downsample_bwd.                                                                        */
+int avdf_chain_fwd_map(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                       const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                       const float* mask, float* const* u, float* const* y, float* const* stats_a,
+                       float* const* stats_b, const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps,
+                       void* stream);
+int avdf_chain_bwd_map(const float* const* dy, const float* const* u, const float* const* stats_b,
+                       const float* const* x, const float* const* stats_a, const float* const* gamma_a,
+                       const float* const* beta_a, const float* const* w, const float* const* gamma_b,
+                       const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
+                       const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream);
 /* dst[s][i] (+)= sum over rows r < nrow and sources j < nsrc[s] of ws[r*row_stride + src_off[s*3+j] + i],
  * i < len[s]; up to 16 segments per launch (host arrays).                                                   */
 int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,

@@ -811,3 +811,42 @@ def test_tuned_extra_rows_swap_plans_at_run_time(ops):
     finally:
         check(lib.avdf_tuned_extra(None), "tuned_extra")
     close(ops.conv1d(xd, wd), ref, "forward with the table restored")
+
+
+@pytest.mark.parametrize("shift,stride", [(1, 1), (3, 1), (-1, 1), (-2, 1), (2, 2)])
+def test_qkv_chain_input_row_map_equals_explicit_resampling(ops, shift, stride):
+    """qkv_chain(xshift=(0, s, s)): the k / v chains read their input through a nearest-resampling row map (the
+    up / down-sampling of the cross-level blocks, backbones.py:487-490) -- forward outputs and every gradient must equal
+    the explicit ops.upsample / ops.downsample followed by the plain chain."""
+    B, T, C = 2, 96, 64
+    Tsrc = (T >> shift) if shift > 0 else (T << -shift)
+    Tout = (T - 1) // stride + 1
+    xq, xkv = rnd(B, T, C, seed=1), rnd(B, Tsrc, C, seed=2)
+    la = [(1 + 0.2 * rnd(1, C, 1, seed=10 + i), 0.2 * rnd(1, C, 1, seed=20 + i)) for i in range(3)]
+    dw = [rnd(C, 1, 3, seed=30 + i, scale=0.5) for i in range(3)]
+    lb = [(1 + 0.2 * rnd(1, C, 1, seed=40 + i), 0.2 * rnd(1, C, 1, seed=50 + i)) for i in range(3)]
+    mask = g32(mk_mask(B, Tout, [Tout, Tout - 5]))
+    dys = [g32(rnd(B, Tout, C, seed=60 + i)) for i in range(3)]
+
+    def run(mapped):
+        leaves = [g32(xq, True), g32(xkv, True)] + [g32(t, True) for pr in la for t in pr] + [g32(t, True) for t in dw] + \
+                 [g32(t, True) for pr in lb for t in pr]
+        q, kv = leaves[0], leaves[1]
+        lna = [(leaves[2 + 2 * i], leaves[3 + 2 * i]) for i in range(3)]
+        dws = leaves[8:11]
+        lnb = [(leaves[11 + 2 * i], leaves[12 + 2 * i]) for i in range(3)]
+        if mapped:
+            ys = ops.qkv_chain([q, kv, kv], lna, dws, lnb, mask, stride, 1e-5, xshift=(0, shift, shift))
+        else:
+            r = 1 << abs(shift)
+            kvr = ops.upsample(kv, r) if shift > 0 else ops.downsample(kv, r)
+            ys = ops.qkv_chain([q, kvr, kvr], lna, dws, lnb, mask, stride, 1e-5)
+        sum((y * d).sum() for y, d in zip(ys[:3], dys)).backward()
+        return [y.detach() for y in ys[:3]], [t.grad for t in leaves]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    for a, b in zip(y1, y0):
+        assert torch.equal(a, b), "forward differs from the explicit resampling"
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        close(a, b.cpu(), f"gradient of leaf {i}", rtol=1e-6)
