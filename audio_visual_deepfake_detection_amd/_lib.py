@@ -104,6 +104,7 @@ SIGNATURES = {
     "avdf_chain_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "avdf_chain_bwd_res": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "avdf_chain_bwd_map": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, P]),
+    "avdf_chain_bwd_folds": (I, [I, I]),
     "avdf_reduce_segments": (I, [P, I, I, I, P, P, P, P, I, P]),
     "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "avdf_conv3d_mode": (I, [I]),

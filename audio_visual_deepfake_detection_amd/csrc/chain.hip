@@ -123,7 +123,11 @@ struct ChainBwdArgs {
   const float* ga[3]; const float* ba[3]; const float* w[3]; const float* gb[3];
   float* dx[3];
   const float* dres[3];   // optional: gradient arriving at the same input through the residual path, added into dx
-  int xsh[3]; int xT[3];  // input row map of the forward pass (see ChainFwdArgs); dx stays at the chain's own resolution
+  int xsh[3]; int xT[3];  // input row map of the forward pass (see ChainFwdArgs)
+  // fold[br] (up-sampled inputs, stride 1, 2^xsh dividing the tile): dx[br] is the gradient of the SOURCE rows
+  // ([B, xT, C]) -- the workgroup sums each group of 2^xsh consecutive rows of its tile through LDS instead of storing
+  // them for a separate reduction launch; otherwise dx[br] is at the chain's own resolution
+  int fold[3];
 };
 
 // ws row of a workgroup: [3 branches][7*C]: dgamma_a, dbeta_a, dw (c*3+k order, 3C), dgamma_b, dbeta_b
@@ -253,7 +257,26 @@ __global__ __launch_bounds__(64 * NW) void chain_bwd_kernel(ChainBwdArgs a, cons
         wrow[e] = s;
       }
     }
-    if ((store_mask >> br) & 1) {
+    if (((store_mask >> br) & 1) && a.fold[br]) {
+      // (dubuf is free: every wave is past phase 2 -- the barrier in front of the workspace-row write)
+      const int sh = a.xsh[br];
+#pragma unroll
+      for (int i = 0; i < NR2; ++i) {
+        const int r = wid + i * NW;
+        if (act) st4(dubuf + r * C + c, (ti0 + r < Tin) ? dxacc[i] : f4(0.f));
+        dxacc[i] = f4(0.f);
+      }
+      __syncthreads();
+      const int grp = 1 << sh;
+      for (int j = wid; j < (TI >> sh); j += NW) {
+        const int ts = (ti0 >> sh) + j;
+        if (ts < a.xT[br] && act) {
+          float4 sum = f4(0.f);
+          for (int q = 0; q < grp; ++q) sum = add4(sum, ld4(dubuf + (j * grp + q) * C + c));
+          st4(a.dx[br] + ((size_t)b * a.xT[br] + ts) * C + c, sum);
+        }
+      }
+    } else if ((store_mask >> br) & 1) {
 #pragma unroll
       for (int i = 0; i < NR2; ++i) {
         const int t = ti0 + wid + i * NW;
@@ -412,6 +435,12 @@ static int chain_bwd_impl(const float* const* dy, const float* const* u, const f
                           const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
                           const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream);
 
+// 1 if avdf_chain_bwd_map returns dx of a branch with input shift `xshift` at the SOURCE resolution ([B, Tin >> xshift, C]:
+// the row groups are summed inside the kernel), 0 if at the chain's resolution (the caller folds it back)
+extern "C" int avdf_chain_bwd_folds(int xshift, int stride) {
+  return (xshift > 0 && stride == 1 && (1 << xshift) <= g_tile_b && g_tile_b % (1 << xshift) == 0) ? 1 : 0;
+}
+
 extern "C" int avdf_chain_bwd_res(const float* const* dy, const float* const* u, const float* const* stats_b,
                                   const float* const* x, const float* const* stats_a, const float* const* gamma_a,
                                   const float* const* beta_a, const float* const* w, const float* const* gamma_b,
@@ -456,6 +485,10 @@ static int chain_bwd_impl(const float* const* dy, const float* const* u, const f
     AVDF_REQUIRE(aligned16(a.dres[i]) && (!a.dres[i] || ((store_mask >> i) & 1)), "chain_bwd: dres must be 16-byte aligned and belong to a closing branch");
   }
   { const int rc = set_row_map("chain_bwd", xshift, Tin, a.xsh, a.xT); if (rc) return rc; }
+  for (int i = 0; i < 3; ++i) {
+    a.fold[i] = avdf_chain_bwd_folds(a.xsh[i], stride);
+    AVDF_REQUIRE(!a.fold[i] || !a.dres[i], "chain_bwd: a residual gradient cannot join a folded (up-sampled) input");
+  }
   hipStream_t st = (hipStream_t)stream;
   const int tiles = cdiv(Tin, g_tile_b);
 #define LAUNCH_CB2(S_, TI_, NW_)                                                                                     \

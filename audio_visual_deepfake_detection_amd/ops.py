@@ -697,7 +697,10 @@ class QkvChainFn(torch.autograd.Function):
                for d in (dyq, dyk, dyv)]
         # branches whose input is the same tensor are summed in the kernel; the sum is stored by the group's last branch
         store = [not ctx.x_same[0], not ctx.x_same[1], True]
-        dx = [torch.empty((B, Tin, C), dtype=torch.float32, device=dev) if st else None for st in store]
+        # (an up-sampled input whose row groups the kernel sums itself gets its gradient at the SOURCE resolution)
+        folds = [bool(sh > 0 and lib.avdf_chain_bwd_folds(sh, stride)) for sh in ctx.xshift]
+        dx = [(torch.empty_like(xs[i]) if folds[i] else torch.empty((B, Tin, C), dtype=torch.float32, device=dev)) if st else None
+              for i, st in enumerate(store)]
         store_mask = sum(1 << i for i, st in enumerate(store) if st)
         wsb = _ws(lib.avdf_chain_bwd_ws(B, Tin, C), xs[0])
         res = [None, None, None]
@@ -712,7 +715,7 @@ class QkvChainFn(torch.autograd.Function):
             # dx of a resampled input is at the chain's resolution: fold it back to the source rows (the backward of the
             # nearest up / down-sampling that the forward skipped)
             for i, sh in enumerate(ctx.xshift):
-                if sh == 0 or dx[i] is None:
+                if sh == 0 or dx[i] is None or folds[i]:
                     continue
                 src = torch.empty_like(xs[i])
                 if sh > 0:

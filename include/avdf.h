@@ -396,6 +396,9 @@ int avdf_chain_fwd_map(const float* const* x, const float* const* gamma_a, const
                        const float* mask, float* const* u, float* const* y, float* const* stats_a,
                        float* const* stats_b, const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps,
                        void* stream);
+/* 1 if avdf_chain_bwd_map hands back dx of a branch with input shift `xshift` at the SOURCE resolution [B, Tin >> xshift, C]
+ * (groups of 2^xshift rows summed inside the kernel), 0 if at the chain's resolution [B, Tin, C].              */
+int avdf_chain_bwd_folds(int xshift, int stride);
 int avdf_chain_bwd_map(const float* const* dy, const float* const* u, const float* const* stats_b,
                        const float* const* x, const float* const* stats_a, const float* const* gamma_a,
                        const float* const* beta_a, const float* const* w, const float* const* gamma_b,
