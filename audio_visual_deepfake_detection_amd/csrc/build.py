@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libavdf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["gemm_conv.hip", "norm.hip", "attn.hip", "pointwise.hip", "smallconv.hip", "loss.hip",
+SOURCES = ["gemm_conv.hip", "pw_gemm.hip", "norm.hip", "attn.hip", "pointwise.hip", "smallconv.hip", "loss.hip",
            "decode_nms.hip", "interp.hip", "optim.hip", "audio.hip", "emotion.hip", "video.hip", "chain.hip", "glue.hip", "api.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"]
@@ -25,7 +25,7 @@ def _stale(obj, deps):
 def build(force=False, verbose=False):
     obj_dir = os.path.join(HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_tuned.inc"),
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "pw_gemm.h"), os.path.join(HERE, "gemm_tuned.inc"),
             os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "avdf.h")]
     jobs = []
     for s in SOURCES:

@@ -40,13 +40,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Standard-normal CDF and exp(-x^2/2) from ONE v_exp_f32 and ONE v_rcp_f32: 0.5*erfc(|x|/sqrt(2)) by the rational form
+// of Abramowitz & Stegun 7.1.26 (5 fmas; |error| <= 3e-7 in fp32 arithmetic, the rounding level of 0.5*(1+erff) itself:
+// exact-erf GELU of libs/modeling/blocks.py:1291 within 4.3e-7 absolute over [-12, 12], as the libm erff form).
+// libm's erff is ~40 instructions with two polynomial branches; the fc1 epilogue and the GELU derivative evaluate this
+// once per element of the [tokens, 4*C] hidden activation.
+__device__ __forceinline__ float normal_cdf_f(float x, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  e = __expf(-0.5f * x * x);
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float h = 0.5f * p * t * e;
+  return x >= 0.0f ? 1.0f - h : h;
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float e;
+  return x * normal_cdf_f(x, e);
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;
+  const float cdf = normal_cdf_f(x, e);
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 __device__ __forceinline__ float act_f(float x, int act) {
   if (act == AVDF_ACT_RELU) return fmaxf(x, 0.0f);

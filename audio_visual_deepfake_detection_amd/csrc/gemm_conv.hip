@@ -26,6 +26,7 @@
 // Replaces: MaskedConv1D / nn.Conv1d(k=1) / nn.Linear of libs/modeling/blocks.py:41-63,
 // 957-966, 1291-1297, 1498-1505 and their autograd-generated backward.
 #include "common.h"
+#include "pw_gemm.h"
 #include <stdlib.h>
 
 // phase-timestamp hook for tools/probe (empty in the product build)
@@ -171,7 +172,14 @@ struct FwdPtrs {
   const float* res = nullptr; const float* rscale = nullptr; const float* rkeep = nullptr; float* yres = nullptr; int resT = 1;
   long bbs = 0;            // bias batch stride in floats (grouped convs: batch = channel group)
 };
-struct DgradPtrs { const float* dy[3]; const float* w[3]; const float* mask[3]; const float* ypre[3]; float* dx[3]; };
+struct DgradPtrs {
+  const float* dy[3]; const float* w[3]; const float* mask[3]; const float* ypre[3]; float* dx[3];
+  // optional epilogue: dx *= xact'(xpre) -- the activation derivative of the layer that PRODUCED this layer's input,
+  // folded into this data gradient (the GELU between fc1 and fc2: evaluated once per element here instead of once per
+  // tile visit in the prologues of the producer's own backward GEMMs)
+  const float* xpre[3] = {nullptr, nullptr, nullptr};
+  int xact = AVDF_ACT_NONE;
+};
 struct WgradPtrs { const float* dy[3]; const float* x[3]; const float* mask[3]; const float* ypre[3]; float* out[3]; float* dbias[3]; };
 template <class T>
 __device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0] : (p == 1 ? a[1] : a[2]); }
@@ -756,18 +764,26 @@ __device__ __forceinline__ void conv_dgrad_body(
       }
     }
   }
-  const bool vec = ((Cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+  const float* __restrict__ xpre = pick3(ptrs.xpre, prob);
+  const int xact = ptrs.xact;
+  const bool vec = ((Cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(xpre) & 15) == 0);
   tile_epilogue<BM, BN, KG, WN, MI, NI>(acc, smem, kg, wm, wn, li, lh, tid, [&](int row_, int cc, float4 v) {
     const int tp = tp0 + row_, c = c0 + cc;
     if (tp >= Tin || c >= Cin) return;
-    float* o = dx + ((size_t)b * Tin + tp) * Cin + c;
+    const size_t off = ((size_t)b * Tin + tp) * Cin + c;
+    float* o = dx + off;
     if (vec && c + 3 < Cin) {
+      if (xpre) {
+        const float4 p = ld4(xpre + off);
+        v.x *= act_grad_f(p.x, xact); v.y *= act_grad_f(p.y, xact); v.z *= act_grad_f(p.z, xact); v.w *= act_grad_f(p.w, xact);
+      }
       *reinterpret_cast<float4*>(o) = v;
     } else {
       const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (c + j < Cin) o[j] = e[j];
+        if (c + j < Cin) o[j] = xpre ? e[j] * act_grad_f(xpre[off + j], xact) : e[j];
     }
   });
 }
@@ -1246,6 +1262,7 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
     const int mk_[7] = {1, 2, 4, 4, 2, 4, 4};
     if (g_override[kind][0] >= 0) {
       TilePlan o{g_override[kind][0], g_override[kind][1] & 7, (g_override[kind][1] >> 3) & 1};
+      if (o.tile >= 8) return o;                         // pipelined pointwise core (pw_gemm.hip): (8 + cfg, stages)
       if (o.tile > 6) o.tile = 6;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
@@ -1378,7 +1395,26 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
   if (K == 1 && stride == 1 && pad == 0 && xbs < 0 && ybs < 0 && wbs == 0) { Tin = Tout = B * Tin; B = 1; }
   if (xbs < 0) xbs = (long)Tin * ldx;
   if (ybs < 0) ybs = (long)Tout * ldy;
-  const TilePlan plan = pick_tile(B * nprob, Tout, Cout, false, K, stride, Cin);
+  TilePlan plan = pick_tile(B * nprob, Tout, Cout, false, K, stride, Cin);
+  if (plan.tile >= 8) {
+    // tile codes >= 8 select the pipelined pointwise core: plain row-major GEMM over the token rows, exact fp32 only
+    const bool ok = K == 1 && stride == 1 && pad == 0 && B == 1 && wbs == 0 && ldx == Cin && ldw == Cin && ldy == Cout &&
+                    Cin % 32 == 0 && Cout % 4 == 0 && ptrs.bbs == 0 && !(g_gemm_mode & 1) && plan.tile - 8 < pw_fwd_cfg_count() &&
+                    aligned16(ptrs.y[0]) && aligned16(ptrs.ypre[0]) && aligned16(ptrs.bias[0]) && aligned16(ptrs.res) &&
+                    aligned16(ptrs.yres) && aligned16(ptrs.rscale) && aligned16(ptrs.y[1]) && aligned16(ptrs.y[2]) &&
+                    aligned16(ptrs.bias[1]) && aligned16(ptrs.bias[2]);
+    if (ok) {
+      PwFwd a;
+      for (int i = 0; i < 3; ++i) {
+        a.x[i] = ptrs.x[i]; a.w[i] = ptrs.w[i]; a.bias[i] = ptrs.bias[i]; a.mask[i] = ptrs.mask[i];
+        a.y[i] = ptrs.y[i]; a.ypre[i] = ptrs.ypre[i];
+      }
+      a.res = ptrs.res; a.rscale = ptrs.rscale; a.rkeep = ptrs.rkeep; a.yres = ptrs.yres; a.resT = ptrs.resT;
+      a.nprob = nprob; a.M = Tout; a.N = Cout; a.K = Cin; a.act = act;
+      return pw_fwd_launch(a, plan.tile - 8, plan.kg, st);
+    }
+    plan = TilePlan{2, 1, 0};
+  }
 #define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
   do {                                                                                                  \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \
@@ -1740,6 +1776,16 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
                                             const float* const* mask, const float* const* ypre, float* const* dx,
                                             float* const* dw, float* const* dbias, int B, int T, int Cin, int Cout,
                                             int act, void* stream) {
+  return avdf_conv1d_bwd_pair_dact(n, dy, w, x, mask, ypre, dx, dw, dbias, nullptr, AVDF_ACT_NONE, B, T, Cin, Cout, act, stream);
+}
+
+// The same with the producer's activation derivative folded into the data gradient: dx[i] = (g w) * xact'(xpre[i]),
+// xpre[i] [B, T, Cin] = the pre-activation tensor whose activation produced this layer's input x[i] (fc2 of an MLP:
+// x = GELU(xpre), xpre = fc1's pre-activation; the next backward GEMM pair then runs on dx as it is, act = NONE).
+extern "C" int avdf_conv1d_bwd_pair_dact(int n, const float* const* dy, const float* const* w, const float* const* x,
+                                         const float* const* mask, const float* const* ypre, float* const* dx,
+                                         float* const* dw, float* const* dbias, const float* const* xpre, int xact, int B,
+                                         int T, int Cin, int Cout, int act, void* stream) {
   AVDF_REQUIRE(n >= 1 && n <= 3 && dy && w && x && dx && dw, "conv1d_bwd_pair: 1..3 problems, non-null tables");
   AVDF_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0, "conv1d_bwd_pair: bad dims");
   AVDF_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv1d_bwd_pair: Cin,Cout must be multiples of 4 (%d,%d)", Cin, Cout);
@@ -1752,9 +1798,11 @@ extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const
     g.dy[i] = dy[j]; g.x[i] = x[j]; g.out[i] = dw[j]; g.dbias[i] = dbias ? dbias[j] : nullptr;
     d.mask[i] = g.mask[i] = mask ? mask[j] : nullptr;
     d.ypre[i] = g.ypre[i] = ypre ? ypre[j] : nullptr;
+    d.xpre[i] = xpre ? xpre[j] : nullptr;
     AVDF_REQUIRE(aligned16(d.dy[i]) && aligned16(d.w[i]) && aligned16(g.x[i]) && aligned16(d.ypre[i]),
                  "conv1d_bwd_pair: 16-byte alignment");
   }
+  d.xact = xpre ? xact : AVDF_ACT_NONE;
   hipStream_t st = (hipStream_t)stream;
   T = B * T; B = 1;                                                  // plain GEMM over the token rows
   WgradPlan p = wgrad_plan(B, T, Cin, Cout, 1, n, 1);

@@ -1,0 +1,415 @@
+// Pipelined exact-fp32 GEMM core for the pointwise layers (Conv1d k=1 / Linear: q, k, v, proj, fc1, fc2 of every
+// transformer block, libs/modeling/blocks.py:957-966, 1291-1297) on v_mfma_f32_32x32x2_f32.
+//
+// Why a second core beside gemm_conv.hip: those kernels stage global -> registers -> LDS with two barriers per K-tile,
+// park the accumulators in LDS for the epilogue, and at K = 256 spend more time in the load / store / barrier phases
+// than in MFMAs (45-65 % of the fp32 matrix peak on the [6144, 256] x [256, 1024] launches).  Here
+//   * operand tiles that need no transformation go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
+//     registers, no ds_write pass, and the loads of K-step k+1 (k+2 with three stages) are in flight under the MFMAs
+//     of step k across ONE raw s_barrier per step (counted vmcnt, never a drain inside the loop);
+//   * the LDS image is lane-linear (a DMA wave-instruction writes 1 KiB contiguously), so the bank swizzle sits on the
+//     SOURCE address: 16-byte piece p of row r is fetched into slot p ^ ((r >> 1) & 7) of the row's 128 bytes and the
+//     fragment reads apply the same XOR -- a 16-lane group of a ds_read_b128 then covers all 64 banks exactly once;
+//   * a lane's ds_read_b128 holds FOUR k-steps of its operand row (MFMA j of an 8-deep step contracts
+//     k = {8q + j, 8q + 4 + j}, the same pairing for A and B);
+//   * the epilogue stores straight from the accumulators: a register of a 32x32 tile is 2 rows x 32 consecutive columns,
+//     i.e. two whole 128-byte lines per store instruction -- no LDS round trip, no barrier;
+//   * workgroups are 256 threads (one wave per SIMD), 2-5 co-resident per CU: while one sits in its prologue or
+//     epilogue the others keep the matrix pipe busy.
+// The operand that carries a prologue in the backward GEMMs (g = dy * mask * act'(pre)) is staged through registers
+// instead (one register set, written after the step's barrier), with the same swizzle.
+#include "pw_gemm.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+// 64 lanes x 16 bytes: lane l's 16 bytes land at lds_base + 16*l (the LDS base is wave-uniform)
+__device__ __forceinline__ void glds16(const float* g, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)lds_base, 16, 0, 0);
+}
+// s_waitcnt vmcnt(N) as the BUILTIN (simm16: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; expcnt / lgkmcnt
+// left at their maxima): the compiler's own wait-count pass sees a real S_WAITCNT and credits it, so it does not add a
+// vmcnt(0) of its own in front of the fragment reads of the stage this wait retires (an inline-asm wait is opaque to it)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+// Fragment reads as inline asm: hipcc orders every compiler-visible ds_read behind ALL pending LDS-DMAs with a vmcnt(0)
+// of its own (it cannot tell the stage being read from the stages being filled), which would drain the prefetch at every
+// K-step.  An asm read is invisible to that pass; the waits are placed by hand: the counted vmcnt + barrier that retire a
+// stage before its reads, lds_wait() + a scheduling fence between the reads and the MFMAs that consume them.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lds_read16(unsigned byte_addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ float f4e(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+constexpr int BK = 32;                      // floats of K per stage: one 128-byte line per tile row
+
+// blocks b and b + 8 share an XCD (round-robin dispatch): give the blocks of one XCD a contiguous run of tile ids, so
+// the column tiles of one row panel (consecutive ids) hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int G) {
+  const int q = G >> 3, r = G & 7, xcd = b & 7, j = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <class T>
+__device__ __forceinline__ T pick3(T const (&a)[3], int p) { return p == 0 ? a[0] : (p == 1 ? a[1] : a[2]); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward:  y[M, N] = act(x[M, K] w[N, K]^T + bias) * mask
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent workgroups of 4 waves: each loops over BM x BN output tiles; the LDS-DMA stream runs ST-1 K-steps ahead of
+// the MFMAs and crosses tile boundaries (the first stages of tile i+1 are in flight during the epilogue of tile i), so
+// the load latency is paid once per workgroup, not once per tile.  The epilogue stores straight from the accumulators
+// (a register = 2 rows x 32 consecutive columns = two whole 128-byte lines), all of its global LOADS issued before its
+// first store: vmcnt retires in issue order, a load behind a store would wait for the store.  The waits of the next
+// tile's first ST-1 steps allow for the epilogue's stores (they are younger than the prefetched DMAs), so the stores drain
+// under the next tile's MFMAs.  Co-resident workgroups start staggered (`stagger`) so that they are not all in their
+// epilogues at once.
+template <int WM, int WN, int KG, int MI, int NI, int ST>
+struct PwGeom {
+  static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  static constexpr int STAGE = (BM + BN) * BK;                  // floats per stage
+  static constexpr int NPS = (BM + BN) / 32;                    // DMA wave-instructions per wave per stage
+  static constexpr int TILE = BM * BN;                          // floats of an output tile
+  static constexpr int LDS_FLOATS = ST * STAGE + (KG - 1) * TILE;   // stages | (KG-1) reduction tiles
+  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+// s_waitcnt vmcnt(n) for a run-time n: rounded DOWN to the next supported immediate (waiting for more is always safe)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  if (n >= 56) wait_vmcnt<56>();
+  else if (n >= 48) wait_vmcnt<48>();
+  else if (n >= 40) wait_vmcnt<40>();
+  else if (n >= 36) wait_vmcnt<36>();
+  else if (n >= 32) wait_vmcnt<32>();
+  else if (n >= 24) wait_vmcnt<24>();
+  else if (n >= 20) wait_vmcnt<20>();
+  else if (n >= 16) wait_vmcnt<16>();
+  else if (n >= 12) wait_vmcnt<12>();
+  else if (n >= 8) wait_vmcnt<8>();
+  else if (n >= 6) wait_vmcnt<6>();
+  else if (n >= 4) wait_vmcnt<4>();
+  else if (n >= 3) wait_vmcnt<3>();
+  else if (n >= 2) wait_vmcnt<2>();
+  else if (n >= 1) wait_vmcnt<1>();
+  else wait_vmcnt<0>();
+}
+
+// diagnostic stamps (tools/pwgemm_bench.py --clock): per workgroup {s_memtime, s_memrealtime} at entry and exit; the
+// in-kernel shader clock is d(memtime) / d(memrealtime) x 100 MHz.  NULL in production (one uniform branch per workgroup).
+__device__ unsigned long long* g_pw_stamps = nullptr;
+
+template <int WM, int WN, int KG, int MI, int NI, int ST>
+__global__ __launch_bounds__(256) void pw_fwd_kernel(PwFwd a, int tilesM, int tilesN, int total, int stagger) {
+  unsigned long long* const stamps = g_pw_stamps;
+  unsigned long long t0 = 0, r0 = 0;
+  if (stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  static_assert(WM * WN * KG == 4, "four waves per workgroup");
+  static_assert(ST == 2 || ST == 3 || ST == 4, "2-4 stages");
+  using Gm = PwGeom<WM, WN, KG, MI, NI, ST>;
+  constexpr int BM = Gm::BM, BN = Gm::BN, STAGE = Gm::STAGE, NPS = Gm::NPS;
+  __shared__ __attribute__((aligned(1024))) float smem[Gm::LDS_FLOATS];
+  float* const red = smem + ST * STAGE;                         // [(KG-1)][wave-major accumulators]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int kg = wid / (WM * WN), wp = wid % (WM * WN), wm = wp / WN, wn = wp % WN;
+  const int G = gridDim.x;
+  const int M = a.M, N = a.N, K = a.K, nk = K / BK;
+  const int per = tilesM * tilesN;
+  auto coords = [&](int L, int& prob, int& m0, int& n0) {       // tile L -> (problem, m0, n0)
+    int t = xcd_remap(L, total);
+    prob = t / per;
+    t -= prob * per;
+    m0 = (t / tilesN) * BM;
+    n0 = (t % tilesN) * BN;
+  };
+  if (stagger > 0) {
+    const int rank = blockIdx.x >> 8;                           // blocks b, b + 256, ... tend to share a CU
+    for (int i = 0; i < rank * stagger; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+
+  // DMA sources of the tile being ISSUED (runs up to ST-1 stages ahead of the tile being computed)
+  const float* srcA[BM / 32];
+  const float* srcB[BN / 32];
+  auto setup = [&](int L) {
+    int prob, m0, n0;
+    coords(L, prob, m0, n0);
+    const float* __restrict__ x = pick3(a.x, prob);
+    const float* __restrict__ w = pick3(a.w, prob);
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {                         // instruction q covers rows 8q .. 8q+7 (8 lanes per 128-B row)
+      const int row = (wid + 4 * i) * 8 + (lane >> 3), piece = (lane & 7) ^ ((row >> 1) & 7);
+      int gm = m0 + row;
+      gm = gm < M ? gm : M - 1;
+      srcA[i] = x + (size_t)gm * K + piece * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int row = (wid + 4 * i) * 8 + (lane >> 3), piece = (lane & 7) ^ ((row >> 1) & 7);
+      int gn = n0 + row;
+      gn = gn < N ? gn : N - 1;
+      srcB[i] = w + (size_t)gn * K + piece * 4;
+    }
+  };
+  int Li = blockIdx.x, ikt = 0, ibuf = 0;
+  bool ivalid = Li < total;
+  if (ivalid) setup(Li);
+  auto issue_next = [&]() -> int {
+    if (!ivalid) return 0;
+    float* sA = smem + ibuf * STAGE;
+    float* sB = sA + BM * BK;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) glds16(srcA[i] + ikt * BK, sA + (wid + 4 * i) * 256);
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) glds16(srcB[i] + ikt * BK, sB + (wid + 4 * i) * 256);
+    ibuf = ibuf + 1 == ST ? 0 : ibuf + 1;
+    if (++ikt == nk) {
+      ikt = 0;
+      Li += G;
+      ivalid = Li < total;
+      if (ivalid) setup(Li);
+    }
+    return 1;
+  };
+
+  // fragment byte offsets inside a stage: row * 128 + ((2q + lh) ^ swz(row)) * 16, q = 0..3
+  unsigned offA[MI], swA[MI], offB[NI], swB[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = (wm * MI + mi) * 32 + li;
+    offA[mi] = row * (BK * 4);
+    swA[mi] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = (wn * NI + ni) * 32 + li;
+    offB[ni] = (BM + row) * (BK * 4);
+    swB[ni] = (row >> 1) & 7;
+  }
+  const unsigned sbase = lds_addr(smem);
+  floatx16 acc[MI * NI];
+  auto compute = [&](int buf) {
+    constexpr int NQ = 4 / KG;
+    const unsigned sb = sbase + buf * (STAGE * 4);
+    f32x4 a4[NQ][MI], b4[NQ][NI];
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const unsigned pc = 2 * (kg + qq * KG) + lh;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a4[qq][mi] = lds_read16(sb + offA[mi] + ((pc ^ swA[mi]) << 4));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b4[qq][ni] = lds_read16(sb + offB[ni] + ((pc ^ swB[ni]) << 4));
+    }
+    lds_wait();
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq][mi][j], b4[qq][ni][j], acc[mi * NI + ni], 0, 0, 0);
+  };
+
+  const float* __restrict__ res = a.res;
+  const float* __restrict__ rscale = a.rscale;
+  const float* __restrict__ rkeep = a.rkeep;
+  float* __restrict__ yres = a.yres;
+  const int act = a.act & 255, resT = a.resT;
+
+  int ahead = 0;                                                // stages issued and not yet consumed
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s) ahead += issue_next();
+  int rbuf = 0;
+  int pend = 0;                                                 // stores of the previous tile's epilogue (this wave)
+  for (int L = blockIdx.x; L < total; L += G) {
+#pragma unroll
+    for (int i = 0; i < MI * NI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      // the stage about to be read has landed once only the (ahead - 1) younger stages' DMAs -- and, for the stages that
+      // were prefetched before the previous tile's epilogue, that epilogue's stores -- are outstanding
+      wait_vmcnt_dyn((ahead - 1) * NPS + (kt < ST - 1 ? pend : 0));
+      __builtin_amdgcn_s_barrier();                             // every wave's part has landed; the stage read last step is free
+      ahead += issue_next();
+      compute(rbuf);
+      rbuf = rbuf + 1 == ST ? 0 : rbuf + 1;
+      --ahead;
+    }
+    pend = 0;
+    if (KG > 1) {                                               // fold the K-groups into group 0 through LDS
+      __builtin_amdgcn_s_barrier();                             // (the previous tile's reduction reads are long done)
+      if (kg > 0) {
+#pragma unroll
+        for (int i = 0; i < MI * NI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((kg - 1) * (WM * WN) + wp) * MI * NI + i) * 1024 + r * 64 + lane] = acc[i][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kg == 0) {
+        const unsigned rb = lds_addr(red) + ((wp * MI * NI) * 1024 + lane) * 4;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+          for (int i = 0; i < MI * NI; ++i) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[r]) : "v"(rb + ((g - 1) * (WM * WN) * MI * NI + i) * 4096), "n"(r * 256));
+            lds_wait();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += v[r];
+          }
+      }
+    }
+    if (kg == 0) {
+      int prob, m0, n0;
+      coords(L, prob, m0, n0);
+      const float* __restrict__ bias = pick3(a.bias, prob);
+      const float* __restrict__ mask = pick3(a.mask, prob);
+      float* __restrict__ y = pick3(a.y, prob);
+      float* __restrict__ ypre = pick3(a.ypre, prob);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int rbase = m0 + (wm * MI + mi) * 32 + 4 * lh;
+        // ---- loads first: row factors, column factors, residual
+        float mk[16], kp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          mk[r] = (mask && row < M) ? mask[row] : 1.f;
+          kp[r] = (res && rkeep && row < M) ? rkeep[row / resT] : 1.f;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = n0 + (wn * NI + ni) * 32 + li;
+          const bool cok = col < N;
+          const float bv = (bias && cok) ? bias[col] : 0.f;
+          const float rs = (res && cok) ? rscale[col] : 0.f;
+          float rv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            rv[r] = (res && cok && row < M) ? res[(size_t)row * N + col] : 0.f;
+          }
+          // ---- then only stores
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row >= M || !cok) continue;
+            const size_t o = (size_t)row * N + col;
+            float v = acc[mi * NI + ni][r] + bv;
+            if (ypre) ypre[o] = v;
+            v = act_f(v, act) * mk[r];
+            if (y) y[o] = v;
+            if (res) yres[o] = fmaf(rs * kp[r], v, rv[r]);
+          }
+          pend += 16 * ((ypre ? 1 : 0) + (y ? 1 : 0) + (res ? 1 : 0));
+        }
+      }
+    }
+  }
+  if (stamps && threadIdx.x == 0) {
+    stamps[blockIdx.x * 4 + 0] = t0;
+    stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+    stamps[blockIdx.x * 4 + 2] = r0;
+    stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+struct PwCfg { int wm, wn, kg, mi, ni; };
+// index = plan code; BM = wm*mi*32, BN = wn*ni*32
+constexpr PwCfg kPwCfgs[] = {
+    {2, 2, 1, 2, 2},   // 0: 128 x 128
+    {2, 2, 1, 2, 1},   // 1: 128 x 64
+    {2, 2, 1, 1, 2},   // 2:  64 x 128
+    {2, 2, 1, 1, 1},   // 3:  64 x 64
+    {2, 1, 2, 1, 1},   // 4:  64 x 32, two K-groups
+    {1, 2, 2, 1, 1},   // 5:  32 x 64, two K-groups
+    {2, 1, 2, 1, 2},   // 6:  64 x 64, two K-groups (waves 32 x 64)
+    {1, 1, 4, 1, 1},   // 7:  32 x 32, four K-groups
+    {1, 1, 4, 1, 2},   // 8:  32 x 64, four K-groups
+    {2, 1, 2, 2, 2},   // 9: 128 x 64, two K-groups (waves 64 x 64)
+};
+constexpr int kNumPwCfgs = sizeof(kPwCfgs) / sizeof(kPwCfgs[0]);
+
+static int g_pw_stagger = [] { const char* e = getenv("AVDF_PW_STAGGER"); return e ? atoi(e) : 0; }();
+static int g_pw_wpc = [] { const char* e = getenv("AVDF_PW_WPC"); return e ? atoi(e) : 0; }();
+
+template <int WM, int WN, int KG, int MI, int NI, int ST>
+int pw_fwd_go2(const PwFwd& a, hipStream_t st) {
+  using Gm = PwGeom<WM, WN, KG, MI, NI, ST>;
+  const int tilesM = cdiv(a.M, Gm::BM), tilesN = cdiv(a.N, Gm::BN);
+  const int total = tilesM * tilesN * a.nprob;
+  // persistent grid: as many workgroups as fit the chip at once (LDS-limited), every one loops over tiles
+  int wpc = (160 * 1024) / Gm::LDS_BYTES;
+  if (wpc > 5) wpc = 5;
+  if (g_pw_wpc > 0 && wpc > g_pw_wpc) wpc = g_pw_wpc;
+  if (wpc < 1) wpc = 1;
+  int grid = 256 * wpc;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL((pw_fwd_kernel<WM, WN, KG, MI, NI, ST>), dim3(grid), dim3(256), 0, st, a, tilesM, tilesN, total, g_pw_stagger);
+  AVDF_CHECK_LAUNCH("pw_fwd");
+  return AVDF_OK;
+}
+template <int WM, int WN, int KG, int MI, int NI>
+int pw_fwd_go(const PwFwd& a, int stages, hipStream_t st) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  if constexpr (4 * (BM + BN) * BK * 4 + (KG - 1) * BM * BN * 4 <= 80 * 1024) {
+    if (stages >= 4) return pw_fwd_go2<WM, WN, KG, MI, NI, 4>(a, st);
+  }
+  if constexpr (3 * (BM + BN) * BK * 4 + (KG - 1) * BM * BN * 4 <= 80 * 1024) {
+    if (stages >= 3) return pw_fwd_go2<WM, WN, KG, MI, NI, 3>(a, st);
+  }
+  return pw_fwd_go2<WM, WN, KG, MI, NI, 2>(a, st);
+}
+
+}  // namespace
+
+int pw_fwd_cfg_count() { return kNumPwCfgs; }
+
+// diagnostic: device buffer of 4 x u64 per workgroup, or NULL to switch the stamps off
+extern "C" int avdf_pw_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_pw_stamps), &p, sizeof(p));
+  AVDF_REQUIRE(e == hipSuccess, "pw_stamps: %s", hipGetErrorString(e));
+  return AVDF_OK;
+}
+
+int pw_fwd_launch(const PwFwd& a, int cfg, int stages, hipStream_t st) {
+  AVDF_REQUIRE(a.K % BK == 0 && a.K >= BK, "pw_fwd: K must be a multiple of %d (K=%d)", BK, a.K);
+  AVDF_REQUIRE(a.nprob >= 1 && a.nprob <= 3 && a.M > 0 && a.N > 0 && a.N % 4 == 0, "pw_fwd: bad problem (N %% 4 != 0?)");
+  switch (cfg) {
+    case 0: return pw_fwd_go<2, 2, 1, 2, 2>(a, stages, st);
+    case 1: return pw_fwd_go<2, 2, 1, 2, 1>(a, stages, st);
+    case 2: return pw_fwd_go<2, 2, 1, 1, 2>(a, stages, st);
+    case 3: return pw_fwd_go<2, 2, 1, 1, 1>(a, stages, st);
+    case 4: return pw_fwd_go<2, 1, 2, 1, 1>(a, stages, st);
+    case 5: return pw_fwd_go<1, 2, 2, 1, 1>(a, stages, st);
+    case 6: return pw_fwd_go<2, 1, 2, 1, 2>(a, stages, st);
+    case 7: return pw_fwd_go<1, 1, 4, 1, 1>(a, stages, st);
+    case 8: return pw_fwd_go<1, 1, 4, 1, 2>(a, stages, st);
+    case 9: return pw_fwd_go<2, 1, 2, 2, 2>(a, stages, st);
+    default: break;
+  }
+  AVDF_REQUIRE(false, "pw_fwd: unknown tile configuration %d", cfg);
+}

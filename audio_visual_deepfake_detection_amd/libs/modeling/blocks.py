@@ -374,6 +374,9 @@ class _BlockBase(nn.Module):
         else:
             out = ops.affine_residual(skip, out_mask, out, None, sa, ka)
             h = self.ln2(out)
+        if ops.mlp_residual_fusable(h, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, out):
+            return ops.mlp_residual(h, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, out_mask,
+                                    out, sm, km)
         h = ops.conv1d(h, self.mlp[0].weight, self.mlp[0].bias, None, 1, ops.ACT_GELU)
         if ops.FUSE_FC2_RESIDUAL and self.mlp[3].weight.shape[0] == out.shape[-1]:
             return ops.conv1d_residual(h, self.mlp[3].weight, self.mlp[3].bias, out_mask, out, sm, km)

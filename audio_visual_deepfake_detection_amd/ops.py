@@ -373,6 +373,89 @@ class Conv1dResidualFn(torch.autograd.Function):
 
 
 FUSE_FC2_RESIDUAL = True   # blocks._residual_mlp: fc2 + AffineDropPath + residual as one launch
+FUSE_MLP = _os.environ.get("AVDF_FUSE_MLP", "1") != "0"   # engine path: the whole MLP half of a block as one autograd node (MlpResidualFn)
+
+
+class MlpResidualFn(torch.autograd.Function):
+    """out = a + scale[c] * keep[b] * ((fc2(GELU(fc1(x))) + b2) * mask): the MLP half of a transformer block
+    (blocks.py:1291-1297, 1313) as ONE autograd node on the engine path (every parameter has a `main_grad` view).
+    Forward = the two launches of conv1d(act=GELU) + conv1d_residual.  Backward: AffineDropPath + residual, then the fc2
+    data + weight gradient launch with the GELU derivative folded into its data-gradient epilogue
+    (avdf_conv1d_bwd_pair_dact: gelu'(pre1) once per element of the [tokens, 4C] hidden gradient), then the fc1 launch on
+    that tensor as it is.  The per-layer path evaluates gelu' in the prologue of fc1's backward GEMMs instead -- once per
+    tile visit, six times per element for the exp10 shapes."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, mask, a, scale, keep):
+        mains = [_main_grad(t) for t in (w1, b1, w2, b2)]
+        x, w1c, b1c, w2c, b2c, mask, a, keep = _c(x), _c(w1), _c(b1), _c(w2), _c(b2), _c(mask), _c(a), _c(keep)
+        B, T, C = x.shape
+        H, Cout = w1c.shape[0], w2c.shape[0]
+        assert w1c.shape == (H, C, 1) and w2c.shape == (Cout, H, 1) and a.shape == (B, T, Cout), (w1c.shape, w2c.shape, a.shape)
+        sc = scale.contiguous().view(-1)
+        pre1 = torch.empty((B, T, H), dtype=x.dtype, device=x.device)
+        h1 = torch.empty_like(pre1)
+        _timed(_conv_tag("fwd", 1, 1, B, T, H), 2.0 * B * T * H * C, lambda: check(
+            lib.avdf_conv1d_fwd(_p(x), _p(w1c), _p(b1c), None, _p(h1), _p(pre1), B, T, C, T, H, 1, 1, ACT_GELU, _stream()),
+            "conv1d_fwd"), ("fwd", 1, 1, B, T, C, H, 1))
+        h2 = torch.empty((B, T, Cout), dtype=x.dtype, device=x.device)
+        out = torch.empty_like(h2)
+        _timed(_conv_tag("fwd", 1, 1, B, T, Cout), 2.0 * B * T * Cout * H, lambda: check(
+            lib.avdf_conv1d_fwd_residual(_p(h1), _p(w2c), _p(b2c), _p(mask), _p(a), _p(sc), _p(keep), _p(h2), _p(out), B, T, H,
+                                         T, Cout, 1, 1, _stream()), "conv1d_fwd_residual"), ("fwd", 1, 1, B, T, H, Cout, 1))
+        ctx.save_for_backward(x, w1c, w2c, mask, pre1, h1, h2, sc, keep)
+        ctx.dims = (B, T, C, H, Cout)
+        ctx.mains = mains
+        ctx.smain, ctx.sshape = _main_grad(scale), scale.shape
+        ctx.gmode = current_gemm_mode()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        with _IssueMode(getattr(ctx, "gmode", 0)):
+            return MlpResidualFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
+        x, w1, w2, mask, pre1, h1, h2, sc, keep = ctx.saved_tensors
+        B, T, C, H, Cout = ctx.dims
+        mw1, mb1, mw2, mb2 = ctx.mains
+        dout = dout.contiguous()
+        st = _stream()
+        dh2 = torch.empty_like(h2)
+        acc = 1 if ctx.smain is not None else 0
+        ds = None
+        if ctx.needs_input_grad[7]:
+            ds = ctx.smain.view(-1) if acc else torch.empty_like(sc)
+        ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, Cout), h2) if ds is not None else None
+        check(lib.avdf_affine_residual_bwd(_p(dout), None, _p(h2), None, _p(sc), _p(keep), None, _p(dh2), _p(ds), _p(ws), B, T,
+                                           Cout, acc, st), "affine_residual_bwd")
+        g1 = torch.empty_like(pre1)                 # d loss / d pre1 = (dh2 * mask) w2 * gelu'(pre1)
+        _timed("conv_bwdpair_k1s1", 4.0 * B * T * Cout * H, lambda: check(
+            lib.avdf_conv1d_bwd_pair_dact(1, _ptr_table([dh2]), _ptr_table([w2]), _ptr_table([h1]),
+                                          _ptr_table([mask]) if mask is not None else None, None, _ptr_table([g1]),
+                                          _ptr_table([mw2.view(w2.shape)]), _ptr_table([mb2.view(Cout)]),
+                                          _ptr_table([pre1]), ACT_GELU, B, T, H, Cout, ACT_NONE, st), "conv1d_bwd_pair_dact"),
+               ("pair", 1, 1, B, T, H, Cout, 1))
+        dx = torch.empty_like(x)
+        _timed("conv_bwdpair_k1s1", 4.0 * B * T * H * C, lambda: check(
+            lib.avdf_conv1d_bwd_pair_grouped(1, _ptr_table([g1]), _ptr_table([w1]), _ptr_table([x]), None, None,
+                                             _ptr_table([dx]), _ptr_table([mw1.view(w1.shape)]),
+                                             _ptr_table([mb1.view(H)]), B, T, C, H, ACT_NONE, st), "conv1d_bwd_pair"),
+               ("pair", 1, 1, B, T, C, H, 1))
+        return dx, None, None, None, None, None, dout, None if (ds is None or acc) else ds.view(ctx.sshape), None
+
+
+def mlp_residual_fusable(x, w1, b1, w2, b2, a):
+    """MlpResidualFn applies on the engine path only: all four parameters accumulate into flat-buffer views, the block
+    keeps its width (fc2 output = residual width) and the input needs a gradient."""
+    return (FUSE_MLP and BWD_PAIR and not WGRAD_SIDE_STREAM and torch.is_grad_enabled() and x.requires_grad and b1 is not None
+            and b2 is not None and all(_main_grad(t) is not None for t in (w1, b1, w2, b2)) and w2.shape[0] == a.shape[-1]
+            and w1.shape[2] == 1 and w2.shape[2] == 1)
+
+
+def mlp_residual(x, w1, b1, w2, b2, mask, a, scale, keep=None):
+    return MlpResidualFn.apply(x, w1, b1, w2, b2, mask, a, scale, keep)
 
 
 def conv1d_residual(x, w, bias, mask, a, scale, keep=None):

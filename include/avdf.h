@@ -74,6 +74,14 @@ int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const float* con
                                  float* const* dw, float* const* dbias, int B, int T, int Cin, int Cout, int act,
                                  void* stream);
 int avdf_bwd_pair_mode(int mode);
+/* avdf_conv1d_bwd_pair_grouped with the PRODUCER layer's activation derivative folded into the data gradient:
+ * dx[i] = (g w) * xact'(xpre[i]), xpre[i] [B, T, Cin] = the pre-activation whose activation produced x[i].  For the MLP
+ * of a block (fc1 -> GELU -> fc2, libs/modeling/blocks.py:1291-1297) the GELU derivative is then evaluated once per
+ * element here, and fc1's own backward pair runs with act = AVDF_ACT_NONE on dx as it is.                           */
+int avdf_conv1d_bwd_pair_dact(int n, const float* const* dy, const float* const* w, const float* const* x,
+                              const float* const* mask, const float* const* ypre, float* const* dx,
+                              float* const* dw, float* const* dbias, const float* const* xpre, int xact, int B, int T,
+                              int Cin, int Cout, int act, void* stream);
 
 /* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..4, K-groups + 8*double
  * buffer); 2 wgrad: (token splits, K-groups); 4 backward pair: (dgrad tile, K-groups | wgrad splits << 3)); a = -1

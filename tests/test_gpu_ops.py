@@ -517,6 +517,39 @@ def test_residual_ln_matches_torch(ops, B, T, C, masks, main):
         close(got, leaves[i].grad, f"residual_ln {name}", rtol=5e-5)
 
 
+@pytest.mark.parametrize("B,T,C,H,masked", [(2, 96, 64, 256, True), (8, 768, 256, 1024, True), (3, 50, 32, 64, False)])
+def test_mlp_residual_node_matches_torch(ops, B, T, C, H, masked):
+    """The MLP half of a block as one autograd node on the engine path (ops.MlpResidualFn: fc1 -> GELU -> fc2 -> mask ->
+    AffineDropPath -> + residual, blocks.py:1291-1297, 1313), the GELU derivative folded into the fc2 data-gradient
+    epilogue (avdf_conv1d_bwd_pair_dact), against float64 autograd of the same expression."""
+    x, a = rnd(B, T, C, seed=1), rnd(B, T, C, seed=2)
+    w1, b1 = rnd(H, C, 1, seed=3, scale=C ** -0.5), rnd(H, seed=4)
+    w2, b2 = rnd(C, H, 1, seed=5, scale=H ** -0.5), rnd(C, seed=6)
+    scale = rnd(1, C, 1, seed=7, scale=0.3)
+    keep = torch.tensor([1.0 / 0.9 if b % 3 else 0.0 for b in range(B)]).double()
+    m = mk_mask(B, T, [T - 5 * b for b in range(B)]) if masked else None
+    dout = rnd(B, T, C, seed=8)
+    leaves = [t.clone().requires_grad_(True) for t in (x, a, w1, b1, w2, b2, scale)]
+    x6, a6, w16, b16, w26, b26, s6 = leaves
+    h6 = F.gelu(F.conv1d(x6.transpose(1, 2), w16, b16))
+    y6 = F.conv1d(h6, w26, b26).transpose(1, 2)
+    if masked:
+        y6 = y6 * m[..., None]
+    o6 = a6 + s6.view(1, 1, C) * keep.view(B, 1, 1) * y6
+    (o6 * dout).sum().backward()
+    dl = [g32(t, True) for t in (x, a, w1, b1, w2, b2, scale)]
+    for t in dl[2:]:
+        t.main_grad = torch.zeros_like(t)
+    assert ops.mlp_residual_fusable(dl[0], dl[2], dl[3], dl[4], dl[5], dl[1])
+    out = ops.mlp_residual(dl[0], dl[2], dl[3], dl[4], dl[5], g32(m) if masked else None, dl[1], dl[6], g32(keep))
+    close(out, o6, "mlp node out")
+    (out * g32(dout)).sum().backward()
+    close(dl[0].grad, leaves[0].grad, "mlp node dx")
+    close(dl[1].grad, leaves[1].grad, "mlp node da")
+    for i, name in ((2, "dw1"), (3, "db1"), (4, "dw2"), (5, "db2"), (6, "dscale")):
+        close(dl[i].main_grad, leaves[i].grad, f"mlp node {name}", rtol=5e-5)
+
+
 def test_interp_batched_equals_per_clip(ops):
     g = torch.Generator().manual_seed(4)
     bufs = [torch.randn(3, 50, 8, generator=g).cuda(), torch.randn(3, 23, 16, generator=g).cuda(), torch.randn(3, 96, 4, generator=g).cuda()]
