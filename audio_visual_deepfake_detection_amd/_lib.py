@@ -28,6 +28,8 @@ SIGNATURES = {
     "avdf_conv1d_fwd_residual": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_pair_grouped": (I, [I, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_pair_dact": (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "avdf_fpn_tail_fwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P]),
+    "avdf_fpn_tail_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "avdf_bwd_pair_mode": (I, [I]),
     "avdf_conv1d_bwd_weight_grouped": (I, [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(PwFwd a, int tilesM, int ti
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq][mi][j], b4[qq][ni][j], acc[mi * NI + ni], 0, 0, 0);
+            acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[qq][ni][j], a4[qq][mi][j], acc[mi * NI + ni], 0, 0, 0);
   };
 
   const float* __restrict__ res = a.res;
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(PwFwd a, int tilesM, int ti
   for (int s = 0; s < ST - 1; ++s) ahead += issue_next();
   int rbuf = 0;
   int pend = 0;                                                 // stores of the previous tile's epilogue (this wave)
+  unsigned long long ph[4] = {0, 0, 0, 0};                      // diagnostic: cycles in wait+barrier / DMA issue / reads+MFMA / epilogue
   for (int L = blockIdx.x; L < total; L += G) {
 #pragma unroll
     for (int i = 0; i < MI * NI; ++i)
@@ -247,14 +248,20 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(PwFwd a, int tilesM, int ti
     for (int kt = 0; kt < nk; ++kt) {
       // the stage about to be read has landed once only the (ahead - 1) younger stages' DMAs -- and, for the stages that
       // were prefetched before the previous tile's epilogue, that epilogue's stores -- are outstanding
+      unsigned long long c0 = 0, c1 = 0, c2 = 0;
+      if (stamps) c0 = __builtin_amdgcn_s_memtime();
       wait_vmcnt_dyn((ahead - 1) * NPS + (kt < ST - 1 ? pend : 0));
       __builtin_amdgcn_s_barrier();                             // every wave's part has landed; the stage read last step is free
+      if (stamps) c1 = __builtin_amdgcn_s_memtime();
       ahead += issue_next();
+      if (stamps) c2 = __builtin_amdgcn_s_memtime();
       compute(rbuf);
+      if (stamps) { ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += __builtin_amdgcn_s_memtime() - c2; }
       rbuf = rbuf + 1 == ST ? 0 : rbuf + 1;
       --ahead;
     }
     pend = 0;
+    unsigned long long e0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
     if (KG > 1) {                                               // fold the K-groups into group 0 through LDS
       __builtin_amdgcn_s_barrier();                             // (the previous tile's reduction reads are long done)
       if (kg > 0) {
@@ -282,6 +289,10 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(PwFwd a, int tilesM, int ti
       }
     }
     if (kg == 0) {
+      // The MFMAs ran with the WEIGHT fragment as the A operand, so the accumulator tile is y^T: lane li owns token row
+      // m = li of the wave tile and registers 4j .. 4j+3 hold output columns n = 8j + 4*lh + {0..3} -- four consecutive
+      // columns: every store is a 16-byte row piece (4 per tile and output instead of 16 dword stores), bias / residual
+      // are 16-byte loads, and the row factors (mask, drop-path keep) are ONE scalar per lane.
       int prob, m0, n0;
       coords(L, prob, m0, n0);
       const float* __restrict__ bias = pick3(a.bias, prob);
@@ -290,49 +301,57 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(PwFwd a, int tilesM, int ti
       float* __restrict__ ypre = pick3(a.ypre, prob);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int rbase = m0 + (wm * MI + mi) * 32 + 4 * lh;
+        const int row = m0 + (wm * MI + mi) * 32 + li;
+        const bool rok = row < M;
         // ---- loads first: row factors, column factors, residual
-        float mk[16], kp[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          mk[r] = (mask && row < M) ? mask[row] : 1.f;
-          kp[r] = (res && rkeep && row < M) ? rkeep[row / resT] : 1.f;
-        }
+        const float mk = (mask && rok) ? mask[row] : 1.f;
+        const float kp = (res && rkeep && rok) ? rkeep[row / resT] : 1.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          const int col = n0 + (wn * NI + ni) * 32 + li;
-          const bool cok = col < N;
-          const float bv = (bias && cok) ? bias[col] : 0.f;
-          const float rs = (res && cok) ? rscale[col] : 0.f;
-          float rv[16];
+          const int cb = n0 + (wn * NI + ni) * 32 + 4 * lh;
+          float4 bv[4], rs[4], rv[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            rv[r] = (res && cok && row < M) ? res[(size_t)row * N + col] : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            const int col = cb + 8 * j;
+            const bool ok = rok && col < N;
+            bv[j] = (bias && ok) ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs[j] = (res && ok) ? *reinterpret_cast<const float4*>(rscale + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[j] = (res && ok) ? *reinterpret_cast<const float4*>(res + (size_t)row * N + col) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
           // ---- then only stores
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            if (row >= M || !cok) continue;
+          for (int j = 0; j < 4; ++j) {
+            const int col = cb + 8 * j;
+            if (!rok || col >= N) continue;
             const size_t o = (size_t)row * N + col;
-            float v = acc[mi * NI + ni][r] + bv;
-            if (ypre) ypre[o] = v;
-            v = act_f(v, act) * mk[r];
-            if (y) y[o] = v;
-            if (res) yres[o] = fmaf(rs * kp[r], v, rv[r]);
+            const floatx16& c = acc[mi * NI + ni];
+            float4 v = make_float4(c[4 * j] + bv[j].x, c[4 * j + 1] + bv[j].y, c[4 * j + 2] + bv[j].z, c[4 * j + 3] + bv[j].w);
+            if (ypre) *reinterpret_cast<float4*>(ypre + o) = v;
+            if (act == AVDF_ACT_GELU) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+            else if (act != AVDF_ACT_NONE) { v.x = act_f(v.x, act); v.y = act_f(v.y, act); v.z = act_f(v.z, act); v.w = act_f(v.w, act); }
+            v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
+            if (y) *reinterpret_cast<float4*>(y + o) = v;
+            if (res) {
+              const float4 o4 = make_float4(fmaf(rs[j].x * kp, v.x, rv[j].x), fmaf(rs[j].y * kp, v.y, rv[j].y),
+                                            fmaf(rs[j].z * kp, v.z, rv[j].z), fmaf(rs[j].w * kp, v.w, rv[j].w));
+              *reinterpret_cast<float4*>(yres + o) = o4;
+            }
           }
-          pend += 16 * ((ypre ? 1 : 0) + (y ? 1 : 0) + (res ? 1 : 0));
+          pend += 4 * ((ypre ? 1 : 0) + (y ? 1 : 0) + (res ? 1 : 0));
         }
       }
     }
+    if (stamps) ph[3] += __builtin_amdgcn_s_memtime() - e0;
   }
   if (stamps && threadIdx.x == 0) {
-    stamps[blockIdx.x * 4 + 0] = t0;
-    stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-    stamps[blockIdx.x * 4 + 2] = r0;
-    stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    stamps[blockIdx.x * 8 + 0] = t0;
+    stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+    stamps[blockIdx.x * 8 + 2] = r0;
+    stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    stamps[blockIdx.x * 8 + 4] = ph[0];
+    stamps[blockIdx.x * 8 + 5] = ph[1];
+    stamps[blockIdx.x * 8 + 6] = ph[2];
+    stamps[blockIdx.x * 8 + 7] = ph[3];
   }
 }
 
@@ -387,7 +406,7 @@ int pw_fwd_go(const PwFwd& a, int stages, hipStream_t st) {
 
 int pw_fwd_cfg_count() { return kNumPwCfgs; }
 
-// diagnostic: device buffer of 4 x u64 per workgroup, or NULL to switch the stamps off
+// diagnostic: device buffer of 8 x u64 per workgroup, or NULL to switch the stamps off
 extern "C" int avdf_pw_stamps(void* buf) {
   unsigned long long* p = (unsigned long long*)buf;
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_pw_stamps), &p, sizeof(p));

@@ -30,7 +30,14 @@ def gap_levels(fpn_feats, fpn_masks):
     B, _, C = fpn_feats[0].shape
     dev = fpn_feats[0].device
     lens = tuple(int(f.shape[1]) for f in fpn_feats)
-    key = (B, lens, dev)
+    keep = gap_keep(B, lens, dev)
+    x, gmask = ops.gap_concat(list(fpn_feats), list(fpn_masks))
+    return x, gmask, lens, keep
+
+
+def gap_keep(B, lens, dev):
+    """0/1 row vector of the gapped level sequence (0 only at the gap rows), cached per (batch, lengths, device)."""
+    key = (B, tuple(lens), dev)
     keep = _GAP_CACHE.get(key)
     if keep is None:
         off, rows = 0, []
@@ -41,8 +48,7 @@ def gap_levels(fpn_feats, fpn_masks):
         keep[:, torch.cat(rows)] = 1.0
         keep = keep.to(dev)
         _GAP_CACHE[key] = keep
-    x, gmask = ops.gap_concat(list(fpn_feats), list(fpn_masks))
-    return x, gmask, lens, keep
+    return keep
 
 
 def split_levels(y, lens):
@@ -293,8 +299,15 @@ class AVPtTransformerRecovery(nn.Module):
         self._front_input = x
         cls_scores, reco_x, self._front_extra = self._front(x, mask)
         feats, masks = self._run_backbone(x, reco_x, mask, cut_hook)
-        fpn_feats, fpn_masks = self.neck(feats, masks)
-        gx, gmask, lens, keep = gap_levels(fpn_feats, fpn_masks)
+        if hasattr(self.neck, "forward_gapped"):
+            out = self.neck.forward_gapped(feats, masks)
+        else:
+            out = self.neck(feats, masks)
+        if len(out) == 3:                      # fused FPN tail: already the gapped level sequence
+            gx, gmask, lens = out
+            keep = gap_keep(gx.shape[0], lens, gx.device)
+        else:
+            gx, gmask, lens, keep = gap_levels(*out)
         lens = list(lens)
         logits = ops.head_out(self.cls_head.forward_gapped(gx, gmask, keep), lens).squeeze(-1)
         offsets = self.reg_head.forward_gapped(gx, gmask, keep, lens)

@@ -25,10 +25,11 @@ class FPN1D(nn.Module):
                                                groups=out_channel))
             self.fpn_norms.append(LayerNorm(out_channel))
 
-    def forward(self, inputs, fpn_masks):
-        assert len(inputs) == len(self.in_channels) and len(fpn_masks) == len(self.in_channels)
-        laterals = [self.lateral_convs[i](inputs[i + self.start_level], fpn_masks[i + self.start_level])[0]
-                    for i in range(len(self.lateral_convs))]
+    def _laterals(self, inputs, fpn_masks):
+        return [self.lateral_convs[i](inputs[i + self.start_level], fpn_masks[i + self.start_level])[0]
+                for i in range(len(self.lateral_convs))]
+
+    def _tail(self, laterals, fpn_masks):
         r = int(self.scale_factor)
         for i in range(len(laterals) - 1, 0, -1):
             laterals[i - 1] = ops.add_upsampled(laterals[i - 1], laterals[i], r)
@@ -38,3 +39,23 @@ class FPN1D(nn.Module):
             feats += (self.fpn_norms[i](x),)
             masks += (m,)
         return feats, masks
+
+    def forward_gapped(self, inputs, fpn_masks):
+        """The levels as the shared heads consume them.  -> (x [B, sum(T_l + 1), C], mask [B, sum(T_l + 1)], lengths) when the
+        fused tail applies (ops.fpn_tail_fusable: inference / engine path): the top-down adds, depthwise convs and LayerNorms
+        of ALL levels are two launches instead of three per level and the concatenation disappears; otherwise
+        (feats, masks) per level like forward()."""
+        assert len(inputs) == len(self.in_channels) and len(fpn_masks) == len(self.in_channels)
+        laterals = self._laterals(inputs, fpn_masks)
+        dws = [c.conv.weight for c in self.fpn_convs]
+        gammas, betas = [n.weight for n in self.fpn_norms], [n.bias for n in self.fpn_norms]
+        if (int(self.scale_factor) == 2 and self.start_level == 0 and all(n.affine for n in self.fpn_norms)
+                and len({n.eps for n in self.fpn_norms}) == 1 and ops.fpn_tail_fusable(laterals, dws, gammas, betas)):
+            x, gmask = ops.fpn_tail(laterals, [fpn_masks[i] for i in range(len(laterals))], dws, gammas, betas,
+                                    self.fpn_norms[0].eps)
+            return x, gmask, tuple(int(t.shape[1]) for t in laterals)
+        return self._tail(laterals, fpn_masks)
+
+    def forward(self, inputs, fpn_masks):
+        assert len(inputs) == len(self.in_channels) and len(fpn_masks) == len(self.in_channels)
+        return self._tail(self._laterals(inputs, fpn_masks), fpn_masks)

@@ -1233,6 +1233,79 @@ def gap_concat(levels, masks):
     return GapConcatFn.apply(len(levels), *levels, *masks)
 
 
+class FpnTailFn(torch.autograd.Function):
+    """Everything of FPN1D behind the lateral convs, all levels at once (necks.py:62-93): top-down x2 add, masked depthwise
+    k3, LayerNorm, into the gapped level sequence of the shared heads -- two launches forward, three backward
+    (avdf_fpn_tail_fwd / _bwd).  Engine path / inference only: the parameter gradients are accumulated into the flat-buffer
+    views (`main_grad`) with float atomics.  args: n, eps, then n laterals, n masks, n dw weights, n gammas, n betas."""
+
+    @staticmethod
+    def forward(ctx, n, eps, *args):
+        lat = [_c(t) for t in args[0:n]]
+        masks = [_c(t) for t in args[n:2 * n]]
+        dws, gammas, betas = list(args[2 * n:3 * n]), list(args[3 * n:4 * n]), list(args[4 * n:5 * n])
+        B, _, C = lat[0].shape
+        lens = [int(t.shape[1]) for t in lat]
+        Tg = sum(lens) + n
+        dev = lat[0].device
+        need = any(ctx.needs_input_grad)
+        td = torch.empty((B, Tg, C), dtype=torch.float32, device=dev)
+        y = torch.empty_like(td)
+        gmask = torch.empty((B, Tg), dtype=torch.float32, device=dev)
+        u = torch.empty_like(td) if need else None
+        stats = torch.empty((2, B, Tg), dtype=torch.float32, device=dev) if need else None
+        dwc, gc, bc = [_c(t) for t in dws], [_c(t).view(-1) for t in gammas], [_c(t).view(-1) for t in betas]
+        for t in lat + masks + dwc + gc + bc:
+            _p(t)
+        ilens = _int_table(lens)
+        check(lib.avdf_fpn_tail_fwd(n, ilens, _ptr_table(lat), _ptr_table(masks), _ptr_table(dwc), _ptr_table(gc),
+                                    _ptr_table(bc), _p(td), _p(y), _p(gmask), _p(u), _p(stats[0]) if need else None,
+                                    _p(stats[1]) if need else None, B, C, float(eps), _stream()), "fpn_tail_fwd")
+        if need:
+            ctx.save_for_backward(td, u, stats, *masks, *dwc, *gc)
+            ctx.cfg = (n, lens, B, C)
+            ctx.mains = ([_main_grad(t) for t in dws], [_main_grad(t) for t in gammas], [_main_grad(t) for t in betas])
+        ctx.mark_non_differentiable(gmask)
+        return y, gmask
+
+    @staticmethod
+    def backward(ctx, dy, _dmask):
+        n, lens, B, C = ctx.cfg
+        sv = ctx.saved_tensors
+        td, u, stats = sv[0], sv[1], sv[2]
+        masks, dwc, gc = list(sv[3:3 + n]), list(sv[3 + n:3 + 2 * n]), list(sv[3 + 2 * n:3 + 3 * n])
+        mw, mg, mb = ctx.mains
+        assert all(m is not None for m in mw + mg + mb), "FpnTailFn backward needs main_grad views on every FPN parameter"
+        dy = dy.contiguous()
+        dum, dtd = torch.empty_like(td), torch.empty_like(td)
+        dlat = [torch.empty((B, lens[l], C), dtype=torch.float32, device=td.device) for l in range(n)]
+        check(lib.avdf_fpn_tail_bwd(n, _int_table(lens), _p(dy), _p(u), _p(stats[0]), _p(stats[1]), _p(td), _ptr_table(masks),
+                                    _ptr_table(dwc), _ptr_table(gc), _p(dum), _p(dtd), _ptr_table(dlat),
+                                    _ptr_table([m.view(-1) for m in mw]), _ptr_table([m.view(-1) for m in mg]),
+                                    _ptr_table([m.view(-1) for m in mb]), B, C, _stream()), "fpn_tail_bwd")
+        return (None, None, *dlat, *([None] * (4 * n)))
+
+
+def fpn_tail_fusable(laterals, dws, gammas, betas):
+    """The fused FPN tail applies at inference and on the engine path (every FPN parameter accumulates into a flat-buffer
+    view); levels must halve in length and be at most 256 channels wide."""
+    C = laterals[0].shape[-1]
+    lens = [int(t.shape[1]) for t in laterals]
+    if not (FUSE_FPN and C <= 256 and C % 4 == 0 and len(laterals) <= 8 and all(lens[i] == 2 * lens[i + 1] for i in range(len(lens) - 1))):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return all(_main_grad(t) is not None for t in list(dws) + list(gammas) + list(betas))
+
+
+def fpn_tail(laterals, masks, dws, gammas, betas, eps=1e-5):
+    n = len(laterals)
+    return FpnTailFn.apply(n, eps, *laterals, *masks, *dws, *gammas, *betas)
+
+
+FUSE_FPN = _os.environ.get("AVDF_FUSE_FPN", "1") != "0"
+
+
 class HeadOutFn(torch.autograd.Function):
     """y [B, Tg, NC] on the gapped sequence -> [B, P, NC] in point order, optionally relu(y * scale_level)."""
 

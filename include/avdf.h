@@ -74,6 +74,21 @@ int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const float* con
                                  float* const* dw, float* const* dbias, int B, int T, int Cin, int Cout, int act,
                                  void* stream);
 int avdf_bwd_pair_mode(int mode);
+
+/* FPN1D tail of ALL pyramid levels (libs/modeling/necks.py:62-93 after the lateral convs): top-down nearest x2 add,
+ * masked depthwise k3 conv and LayerNorm of every level, written into the gapped level sequence [B, sum(T_l + 1), C] the
+ * shared heads run on (a zero row after each level).  lens[l] = T_l with T_l = 2 T_{l+1}; lat / mask / dw / gamma / beta:
+ * host tables of n device pointers ([B,T_l,C], [B,T_l], [C,1,3], [C], [C]).  td [B,Tg,C]: workspace kept for the backward;
+ * y [B,Tg,C], gmask [B,Tg]; u [B,Tg,C], mean, rstd [B,Tg] saved for the backward (all three NULL at inference).
+ * Backward: dlat[l] [B,T_l,C] overwritten; ddw / dgamma / dbeta tables are ACCUMULATED into (float atomics; NULL = skip);
+ * dum, dtd [B,Tg,C]: workspaces.                                                                                    */
+int avdf_fpn_tail_fwd(int n, const int* lens, const float* const* lat, const float* const* mask, const float* const* dw,
+                      const float* const* gamma, const float* const* beta, float* td, float* y, float* gmask, float* u,
+                      float* mean, float* rstd, int B, int C, float eps, void* stream);
+int avdf_fpn_tail_bwd(int n, const int* lens, const float* dy, const float* u, const float* mean, const float* rstd,
+                      const float* td, const float* const* mask, const float* const* dw, const float* const* gamma,
+                      float* dum, float* dtd, float* const* dlat, float* const* ddw, float* const* dgamma,
+                      float* const* dbeta, int B, int C, void* stream);
 /* avdf_conv1d_bwd_pair_grouped with the PRODUCER layer's activation derivative folded into the data gradient:
  * dx[i] = (g w) * xact'(xpre[i]), xpre[i] [B, T, Cin] = the pre-activation whose activation produced x[i].  For the MLP
  * of a block (fc1 -> GELU -> fc2, libs/modeling/blocks.py:1291-1297) the GELU derivative is then evaluated once per

@@ -550,6 +550,53 @@ def test_mlp_residual_node_matches_torch(ops, B, T, C, H, masked):
         close(dl[i].main_grad, leaves[i].grad, f"mlp node {name}", rtol=5e-5)
 
 
+@pytest.mark.parametrize("B,C,lens,main", [(2, 64, (32, 16, 8), True), (8, 256, (768, 384, 192, 96, 48, 24), True),
+                                           (3, 32, (16, 8), False)])
+def test_fpn_tail_matches_per_level_path(ops, B, C, lens, main):
+    """FPN1D behind the lateral convs, all levels in two launches forward / three backward (ops.fpn_tail), against the
+    per-level reference path in float64: top-down nearest x2 add, masked depthwise k3, LayerNorm (necks.py:62-93), laid out
+    as the gapped level sequence of the shared heads.  main=False: forward only (inference)."""
+    n = len(lens)
+    lat = [rnd(B, T, C, seed=10 + l) for l, T in enumerate(lens)]
+    msk = [mk_mask(B, T, [max(T - (b * 3) % T, 1) for b in range(B)]) for T in lens]
+    dws = [rnd(C, 1, 3, seed=20 + l, scale=0.5) for l in range(n)]
+    gam = [1 + 0.2 * rnd(1, C, 1, seed=30 + l) for l in range(n)]
+    bet = [0.2 * rnd(1, C, 1, seed=40 + l) for l in range(n)]
+    Tg = sum(lens) + n
+    dy = rnd(B, Tg, C, seed=50)
+    leaves = [[t.clone().requires_grad_(True) for t in grp] for grp in (lat, dws, gam, bet)]
+    l6, w6, g6, b6 = leaves
+    td = list(l6)
+    for i in range(n - 1, 0, -1):
+        td[i - 1] = td[i - 1] + td[i].repeat_interleave(2, dim=1)
+    rows, mrows = [], []
+    for l in range(n):
+        u = F.conv1d(td[l].transpose(1, 2), w6[l], None, padding=1, groups=C).transpose(1, 2) * msk[l][..., None]
+        rows += [F.layer_norm(u, (C,), g6[l].view(-1), b6[l].view(-1), 1e-5), torch.zeros(B, 1, C, dtype=torch.float64)]
+        mrows += [msk[l], torch.zeros(B, 1, dtype=torch.float64)]
+    ref, refm = torch.cat(rows, 1), torch.cat(mrows, 1)
+    (ref * dy).sum().backward()
+    dl = [[g32(t, main) for t in grp] for grp in (lat, dws, gam, bet)]
+    if main:
+        for grp in dl[1:]:
+            for t in grp:
+                t.main_grad = torch.zeros_like(t)
+    import contextlib
+    with (contextlib.nullcontext() if main else torch.no_grad()):
+        assert ops.fpn_tail_fusable(dl[0], dl[1], dl[2], dl[3])
+        y, gm = ops.fpn_tail(dl[0], [g32(m) for m in msk], dl[1], dl[2], dl[3], 1e-5)
+    close(y, ref, "fpn tail y")
+    close(gm, refm, "fpn tail mask")
+    if not main:
+        return
+    (y * g32(dy)).sum().backward()
+    for l in range(n):
+        close(dl[0][l].grad, l6[l].grad, f"fpn tail dlat[{l}]")
+        close(dl[1][l].main_grad, w6[l].grad, f"fpn tail ddw[{l}]", rtol=5e-5)
+        close(dl[2][l].main_grad, g6[l].grad, f"fpn tail dgamma[{l}]", rtol=5e-5)
+        close(dl[3][l].main_grad, b6[l].grad, f"fpn tail dbeta[{l}]", rtol=5e-5)
+
+
 def test_interp_batched_equals_per_clip(ops):
     g = torch.Generator().manual_seed(4)
     bufs = [torch.randn(3, 50, 8, generator=g).cuda(), torch.randn(3, 23, 16, generator=g).cuda(), torch.randn(3, 96, 4, generator=g).cuda()]

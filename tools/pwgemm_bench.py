@@ -41,7 +41,7 @@ def fwd_case(name, M, Cin, Cout, nprob, act, has_mask, residual, quick):
     mask = (torch.rand(1, M, generator=g) > 0.2).float().to(dev) if has_mask else None
     res = torch.randn(1, M, Cout, generator=g).to(dev) if residual else None
     rscale = torch.randn(Cout, generator=g).to(dev) if residual else None
-    rkeep = (torch.rand(8, generator=g) > 0.3).float().to(dev) if residual else None
+    rkeep = (torch.rand(8, generator=g) > 0.3).float().to(dev) if residual else None   # 8 drop-path groups of M/8 rows
     ys = [torch.empty(1, M, Cout, device=dev) for _ in range(nprob)]
     ypre = torch.empty(1, M, Cout, device=dev) if act else None
     out = torch.empty(1, M, Cout, device=dev) if residual else None
@@ -106,7 +106,10 @@ def fwd_case(name, M, Cin, Cout, nprob, act, has_mask, residual, quick):
 
 def main():
     quick = "--quick" in sys.argv
-    for sh in SHAPES:
+    shapes = SHAPES
+    if "--b32" in sys.argv:            # the same layers at 32 clips per step
+        shapes = [(n + " x4", 4 * M, ci, co, p, a, hm, r) for (n, M, ci, co, p, a, hm, r) in SHAPES[:4]]
+    for sh in shapes:
         fwd_case(*sh, quick)
 
 
@@ -152,8 +155,9 @@ def clock():
     raw.avdf_pw_stamps.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda:0")
     st = lambda: torch.cuda.current_stream().cuda_stream
-    stamps = torch.zeros(4096 * 4, dtype=torch.int64, device=dev)
-    for name, M, Cin, Cout, cfg, stages, act in (("fc1 768", 6144, 256, 1024, 3, 3, 2), ("fc1 768", 6144, 256, 1024, 3, 2, 2),
+    stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+    for name, M, Cin, Cout, cfg, stages, act in (("fc1 768", 6144, 256, 1024, 3, 3, 2), ("fc1 768", 6144, 256, 1024, 3, 3, 0),
+                                                 ("fc1 768", 6144, 256, 1024, 1, 2, 2),
                                                  ("proj 768", 6144, 256, 256, 5, 2, 0), ("fc2 768", 6144, 1024, 256, 5, 2, 0)):
         x = torch.randn(1, M, Cin, device=dev)
         w = torch.randn(Cout, Cin, 1, device=dev) * Cin ** -0.5
@@ -171,7 +175,7 @@ def clock():
             fn()
         torch.cuda.synchronize()
         raw.avdf_pw_stamps(None)
-        s = stamps.cpu().numpy().reshape(-1, 4)
+        s = stamps.cpu().numpy().reshape(-1, 8)
         s = s[s[:, 3] > 0]
         clk = (s[:, 1] - s[:, 0]) / np.maximum(s[:, 3] - s[:, 2], 1) * 100.0       # MHz
         life = (s[:, 3] - s[:, 2]) / 100.0                                           # us
@@ -180,6 +184,9 @@ def clock():
               f"(p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f}); workgroup life median {np.median(life):.1f} us, "
               f"max {life.max():.1f}; first start -> last end {span:.1f} us; starts spread {(s[:, 2].max() - s[:, 2].min()) / 100.0:.1f} us",
               flush=True)
+        tot = (s[:, 1] - s[:, 0]).astype(float)
+        print("    wave 0 cycles, median share of the workgroup life: wait+barrier %.0f%%  DMA issue %.0f%%  reads+MFMA %.0f%%  epilogue %.0f%%"
+              % tuple(100 * np.median(s[:, 4 + i] / tot) for i in range(4)), flush=True)
         stamps.zero_()
     check(lib.avdf_gemm_override(0, -1, -1), "ovr")
 
