@@ -1,23 +1,28 @@
-// Pipelined exact-fp32 GEMM core for the pointwise layers (Conv1d k=1 / Linear: q, k, v, proj, fc1, fc2 of every
-// transformer block, libs/modeling/blocks.py:957-966, 1291-1297) on v_mfma_f32_32x32x2_f32.
+// Pipelined exact-fp32 GEMM core for the FORWARD of the pointwise layers (Conv1d k=1 / Linear: q, k, v, proj, fc1, fc2 of
+// every transformer block, libs/modeling/blocks.py:957-966, 1291-1297) on v_mfma_f32_32x32x2_f32 -- an alternative to the
+// register-staged kernels of gemm_conv.hip, selected per shape by plan codes >= 8 (table rows / avdf_gemm_override).
 //
-// Why a second core beside gemm_conv.hip: those kernels stage global -> registers -> LDS with two barriers per K-tile,
-// park the accumulators in LDS for the epilogue, and at K = 256 spend more time in the load / store / barrier phases
-// than in MFMAs (45-65 % of the fp32 matrix peak on the [6144, 256] x [256, 1024] launches).  Here
-//   * operand tiles that need no transformation go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging
-//     registers, no ds_write pass, and the loads of K-step k+1 (k+2 with three stages) are in flight under the MFMAs
-//     of step k across ONE raw s_barrier per step (counted vmcnt, never a drain inside the loop);
+//   * persistent workgroups (4 waves) loop over output tiles; operand tiles go global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4): no staging registers, no ds_write pass; the DMA stream runs ST-1 K-steps ahead across
+//     ONE raw s_barrier per step (counted vmcnt) and across tile boundaries;
 //   * the LDS image is lane-linear (a DMA wave-instruction writes 1 KiB contiguously), so the bank swizzle sits on the
 //     SOURCE address: 16-byte piece p of row r is fetched into slot p ^ ((r >> 1) & 7) of the row's 128 bytes and the
 //     fragment reads apply the same XOR -- a 16-lane group of a ds_read_b128 then covers all 64 banks exactly once;
 //   * a lane's ds_read_b128 holds FOUR k-steps of its operand row (MFMA j of an 8-deep step contracts
 //     k = {8q + j, 8q + 4 + j}, the same pairing for A and B);
-//   * the epilogue stores straight from the accumulators: a register of a 32x32 tile is 2 rows x 32 consecutive columns,
-//     i.e. two whole 128-byte lines per store instruction -- no LDS round trip, no barrier;
-//   * workgroups are 256 threads (one wave per SIMD), 2-5 co-resident per CU: while one sits in its prologue or
-//     epilogue the others keep the matrix pipe busy.
-// The operand that carries a prologue in the backward GEMMs (g = dy * mask * act'(pre)) is staged through registers
-// instead (one register set, written after the step's barrier), with the same swizzle.
+//   * the MFMAs take the WEIGHT fragment as the A operand, so the accumulator tile is y^T and a lane's registers 4j..4j+3
+//     are four consecutive output columns of one token row: the epilogue is 16-byte row-piece stores straight from the
+//     accumulators (no LDS round trip, no barrier), 16-byte bias / residual loads, one row factor per lane.
+//
+// Status (round 3, profiles/r03_*pw*): correct on every shape (tests/test_gpu_ops.py, tools/pwgemm_bench.py), but NOT
+// faster than the table plans of gemm_conv.hip -- 0.83-1.03x in isolation at 8 and 32 clips per step -- so no table row
+// selects it.  In-kernel stamps (one workgroup per CU, fc1 at 8 clips) put a K-step at ~2300 cycles for 1024 cycles of
+// MFMA: ~350 cycles to ISSUE four 1 KiB DMAs per wave (the CU's address path serialises them: 16 KB per step is ~40 % of
+// what the L2 -> LDS path of a CU sustains), ~700 in the counted wait + barrier, ~250 in fragment reads before the first
+// MFMA can issue; the row-piece epilogue is 17-22 % of a workgroup's life.  At K = 256 a tile has only eight such steps, so
+// neither core gets past ~50 % of the fp32 matrix peak on these shapes (in-kernel clock 2.1-2.3 GHz under this load, not
+// 2.4).  Kept as the measured starting point of a software-pipelined variant (DMA issue and next-step fragment reads
+// interleaved with the MFMAs of the current step).
 #include "pw_gemm.h"
 #include <stdlib.h>
 
