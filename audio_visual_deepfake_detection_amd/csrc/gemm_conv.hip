@@ -1262,7 +1262,7 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
     const int mk_[7] = {1, 2, 4, 4, 2, 4, 4};
     if (g_override[kind][0] >= 0) {
       TilePlan o{g_override[kind][0], g_override[kind][1] & 7, (g_override[kind][1] >> 3) & 1};
-      if (o.tile >= 8) return o;                         // pipelined pointwise core (pw_gemm.hip): (8 + cfg, stages)
+      if (o.tile >= 8) return o;                         // pipelined pointwise core (pw_gemm.hip): (8 + cfg, workgroups per CU)
       if (o.tile > 6) o.tile = 6;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
@@ -1399,7 +1399,9 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
   if (plan.tile >= 8) {
     // tile codes >= 8 select the pipelined pointwise core: plain row-major GEMM over the token rows, exact fp32 only
     const bool ok = K == 1 && stride == 1 && pad == 0 && B == 1 && wbs == 0 && ldx == Cin && ldw == Cin && ldy == Cout &&
-                    Cin % 32 == 0 && Cout % 4 == 0 && ptrs.bbs == 0 && !(g_gemm_mode & 1) && plan.tile - 8 < pw_fwd_cfg_count() &&
+                    Cout % 4 == 0 && ptrs.bbs == 0 && !(g_gemm_mode & 1) && pw_fwd_supported(plan.tile - 8, Cin) &&
+                    aligned16(ptrs.x[0]) && aligned16(ptrs.x[1]) && aligned16(ptrs.x[2]) && aligned16(ptrs.w[0]) &&
+                    aligned16(ptrs.w[1]) && aligned16(ptrs.w[2]) &&
                     aligned16(ptrs.y[0]) && aligned16(ptrs.ypre[0]) && aligned16(ptrs.bias[0]) && aligned16(ptrs.res) &&
                     aligned16(ptrs.yres) && aligned16(ptrs.rscale) && aligned16(ptrs.y[1]) && aligned16(ptrs.y[2]) &&
                     aligned16(ptrs.bias[1]) && aligned16(ptrs.bias[2]);

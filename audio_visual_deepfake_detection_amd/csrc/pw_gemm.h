@@ -12,6 +12,8 @@ struct PwFwd {
   int nprob, M, N, K, act;
 };
 
-// cfg: tile configuration index (pw_gemm.hip: kPwCfgs); stages 2..4 (LDS permitting)
-int pw_fwd_launch(const PwFwd& a, int cfg, int stages, hipStream_t st);
+// cfg: tile configuration index (pw_gemm.hip: kPwCfgs); wpc: workgroups per CU the persistent grid is sized for (0 = what
+// the configuration's LDS allows, at most 2).  x / w rows must be 16-byte aligned (K % 4 == 0 and aligned bases).
+int pw_fwd_launch(const PwFwd& a, int cfg, int wpc, hipStream_t st);
 int pw_fwd_cfg_count();
+bool pw_fwd_supported(int cfg, int K);

@@ -1,6 +1,6 @@
 """In-situ A/B of the pipelined pointwise GEMM core (csrc/pw_gemm.hip) against the table plans: for each forward K = 1
 shape of the exp10 step, re-capture the training step with the shape's plan row replaced by a pw configuration
-(tile code 8 + cfg, stages) and time the whole step.   python tools/pw_insitu.py   (GPU box)"""
+(tile code 8 + cfg, workgroups per CU) and time the whole step.   python tools/pw_insitu.py   (GPU box)"""
 import ctypes, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ B = 8
 M = B * 768
 SHAPES = [(0, 1, 1, M, 1024, 256), (0, 1, 1, M, 256, 1024), (0, 1, 1, 3 * M, 256, 256), (0, 1, 1, M, 256, 256),
           (0, 1, 1, M // 2, 1024, 256), (0, 1, 1, M // 2, 256, 1024), (0, 1, 1, 3 * M // 2, 256, 256)]
-CANDS = [(8 + c, s) for c in (1, 2, 3, 4, 5) for s in (2, 3)]
+CANDS = [(8 + c, 0) for c in (0, 1, 2, 4, 5, 6)]       # (plan code, workgroups per CU: 0 = what the LDS allows)
 
 
 def main():
@@ -58,9 +58,9 @@ def main():
         res = {}
         for a, b in CANDS:
             res[(a, b)] = measure({key: (a, b)})
-            print(f"  {key} pw cfg {a - 8} stages {b}: {res[(a, b)]:.1f}", flush=True)
+            print(f"  {key} pw cfg {a - 8} wpc {b}: {res[(a, b)]:.1f}", flush=True)
         (a, b), v = max(res.items(), key=lambda kv: kv[1])
-        print(f"{key}: best pw cfg {a - 8} stages {b}: {v:.1f} vs table {base:.1f}", flush=True)
+        print(f"{key}: best pw cfg {a - 8} wpc {b}: {v:.1f} vs table {base:.1f}", flush=True)
         out["shapes"].append({"shape": list(key), "best": [a, b], "clips_per_s": round(v, 1),
                               "all": {f"{x},{y}": round(z, 1) for (x, y), z in res.items()}})
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", "pw_insitu.json"), "w"), indent=1)
