@@ -23,6 +23,9 @@ SIGNATURES = {
     "avdf_gemm_mode": (I, [I]),
     "avdf_gemm_override": (I, [I, I, I]),
     "avdf_tuned_extra": (I, [P]),
+    "avdf_pw_launch_count": (I, []),
+    "avdf_pw_stamps": (I, [P]),
+    "avdf_pw_flags": (I, [I]),
     "avdf_conv1d_fwd_grouped": (I, [I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_bwd_data_grouped": (I, [I, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "avdf_conv1d_fwd_residual": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),

@@ -588,7 +588,7 @@ int pw_fwd_go(const PwFwd& a, int wpc_plan, hipStream_t st) {
 
 }  // namespace
 
-extern "C" long avdf_pw_launch_count() { return g_pw_launches; }
+extern "C" int avdf_pw_launch_count() { return (int)g_pw_launches; }
 
 int pw_fwd_cfg_count() { return kNumPwCfgs; }
 

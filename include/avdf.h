@@ -100,8 +100,16 @@ int avdf_conv1d_bwd_pair_dact(int n, const float* const* dy, const float* const*
 
 /* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..4, K-groups + 8*double
  * buffer); 2 wgrad: (token splits, K-groups); 4 backward pair: (dgrad tile, K-groups | wgrad splits << 3)); a = -1
- * restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only.                                      */
+ * restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only.  Forward plans a >= 8 select the
+ * wave-specialised pointwise core of csrc/pw_gemm.hip for K = 1, stride 1 launches it supports (configuration a - 8,
+ * b = workgroups per CU, 0 = what its LDS allows); launches it does not support keep a table-kernel plan.          */
 int avdf_gemm_override(int kind, int a, int b);
+/* Diagnostics of the pointwise core (tools/pwgemm_bench.py, tests): launches it has served so far; a device buffer of
+ * 8 x uint64 per workgroup x 3 wave roles for its in-kernel s_memtime phase stamps (NULL = off, the default); ablation
+ * switches (2 no epilogue items, 4 no operand DMAs, 8 no priority raise; 0 = off, the default).                     */
+int avdf_pw_launch_count(void);
+int avdf_pw_stamps(void* buf);
+int avdf_pw_flags(int flags);
 /* Tuner hook (tools/plan_search.py): replace the process's AVDF_TUNED_EXTRA plan rows ("kind,K,stride,M,N,Kred,a,b;...";
  * kinds 3 / 5 / 6 = forward / backward pair / dgrad in split-bf16 mode); NULL or "" clears them.                    */
 int avdf_tuned_extra(const char* rows);

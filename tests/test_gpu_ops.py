@@ -606,7 +606,7 @@ def test_pipelined_pointwise_gemm_core(ops, cfg, wpc, shape):
     import ctypes
     from audio_visual_deepfake_detection_amd._lib import lib, check, LIB_PATH
     raw = ctypes.CDLL(LIB_PATH)
-    raw.avdf_pw_launch_count.restype = ctypes.c_long
+    raw.avdf_pw_launch_count.restype = ctypes.c_int
     B, T, Cin, Cout = shape                       # (3, 334, ., 328): M = 1002 rows and 328 columns leave partial tiles
     x, w, b = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, 1, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3)
     m = mk_mask(B, T, [T, T - 40, 7][:B])

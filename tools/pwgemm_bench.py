@@ -15,7 +15,7 @@ from tools.gemm_bench import timeit
 import ctypes
 
 RAW = ctypes.CDLL(LIB_PATH)
-RAW.avdf_pw_launch_count.restype = ctypes.c_long
+RAW.avdf_pw_launch_count.restype = ctypes.c_int
 
 SHAPES = [  # name, M, Cin, Cout, nprob, act, has_mask, residual
     ("fc1 768", 6144, 256, 1024, 1, 2, False, False),
