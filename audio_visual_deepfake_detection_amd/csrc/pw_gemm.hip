@@ -36,6 +36,7 @@
 // columns of one token row, so parking is four ds_write_b128 per 32x32 tile.
 #include "pw_gemm.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -135,8 +136,8 @@ struct PwGeom {
   static constexpr int TILE = BM * BN;
   static constexpr int WAVES = 4 + NL + NE;                     // MFMA waves, loader waves, epilogue waves
   static constexpr int IT = TILE / (NE * 256);                  // float4 items per epilogue-wave lane per tile
-  static constexpr int CPK = IT >= 8 ? IT / 4 : 1;              // static bound of the items per K-step chunk
-  static constexpr int PB = cmax(cmax(BM, BN), 64);             // floats per tile-parameter vector
+  static constexpr int CPK = (IT + 3) / 4;                      // static bound of the items per K-step chunk
+  static constexpr int PB = (cmax(BM, BN) + 63) / 64 * 64;      // floats per tile-parameter vector (whole 64-lane DMA instructions)
   // float offsets of the regions
   static constexpr int EPI = ST * STAGE;                        // parked output tile [BM][LDE]
   static constexpr int RED = EPI + BM * LDE;                    // K-group partials [(KG-1)][wave-major accumulators]
@@ -559,10 +560,12 @@ constexpr PwCfg kPwCfgs[] = {
     {2, 2, 1, 1, 1, 4, 2},   // 6:  64 x 64, 10 waves
     {2, 2, 1, 2, 1, 2, 2},   // 7: 128 x 64, 8 waves
     {2, 2, 1, 2, 1, 4, 2},   // 8: 128 x 64, 10 waves
+    {1, 2, 2, 3, 1, 2, 2},   // 9:  96 x 64, two K-groups (waves 96 x 32), 8 waves: [6144, 256] outputs are 256 tiles, one per CU
+    {1, 2, 2, 3, 1, 4, 4},   // 10: 96 x 64, two K-groups, 12 waves
 };
 constexpr int kNumPwCfgs = sizeof(kPwCfgs) / sizeof(kPwCfgs[0]);
 
-static long g_pw_launches = 0;              // launches so far (tests assert that a forced plan really ran here)
+static std::atomic<int> g_pw_launches{0};   // launches so far (tests assert that a forced plan really ran here)
 static int g_pw_wpc = [] { const char* e = getenv("AVDF_PW_WPC"); return e ? atoi(e) : 0; }();
 
 template <int WM, int WN, int KG, int MI, int NI, int NL, int NE>
@@ -588,7 +591,7 @@ int pw_fwd_go(const PwFwd& a, int wpc_plan, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int avdf_pw_launch_count() { return (int)g_pw_launches; }
+extern "C" int avdf_pw_launch_count() { return g_pw_launches.load(); }
 
 int pw_fwd_cfg_count() { return kNumPwCfgs; }
 
@@ -598,7 +601,7 @@ bool pw_fwd_supported(int cfg, int K) {
   if (cfg < 0 || cfg >= kNumPwCfgs || K % (2 * BK) != 0) return false;
   const PwCfg& c = kPwCfgs[cfg];
   const int nk = K / BK, it = 4 * c.wm * c.mi * c.wn * c.ni / c.ne;          // TILE / (NE * 256)
-  return nk >= ST + 1 && (it + nk - 3) / (nk - 2) <= (it >= 8 ? it / 4 : 1);
+  return nk >= ST + 1 && (it + nk - 3) / (nk - 2) <= (it + 3) / 4;
 }
 
 extern "C" int avdf_pw_flags(int flags) {
@@ -628,6 +631,8 @@ int pw_fwd_launch(const PwFwd& a, int cfg, int wpc, hipStream_t st) {
     case 6: return pw_fwd_go<2, 2, 1, 1, 1, 4, 2>(a, wpc, st);
     case 7: return pw_fwd_go<2, 2, 1, 2, 1, 2, 2>(a, wpc, st);
     case 8: return pw_fwd_go<2, 2, 1, 2, 1, 4, 2>(a, wpc, st);
+    case 9: return pw_fwd_go<1, 2, 2, 3, 1, 2, 2>(a, wpc, st);
+    case 10: return pw_fwd_go<1, 2, 2, 3, 1, 4, 4>(a, wpc, st);
     default: break;
   }
   AVDF_REQUIRE(false, "pw_fwd: unknown tile configuration %d", cfg);

@@ -598,7 +598,7 @@ def test_fpn_tail_matches_per_level_path(ops, B, C, lens, main):
 
 
 @pytest.mark.parametrize("shape", [(3, 334, 256, 328), (2, 1536, 192, 256), (1, 200, 512, 64)])
-@pytest.mark.parametrize("cfg,wpc", [(0, 0), (0, 1), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (8, 0)])
+@pytest.mark.parametrize("cfg,wpc", [(0, 0), (0, 1), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (8, 0), (9, 0), (10, 0)])
 def test_pipelined_pointwise_gemm_core(ops, cfg, wpc, shape):
     """The wave-specialised LDS-DMA forward core of csrc/pw_gemm.hip (plan codes >= 8, forced through the tuner hook):
     ragged and interior M / N tiles, one and several tiles per workgroup, 6 / 8 / 16 K-steps, bias, GELU with the pre-activation copy, row mask, and the fused

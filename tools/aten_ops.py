@@ -28,3 +28,14 @@ rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startsw
 rows.sort(key=lambda e: -e.count)
 for e in rows[:60]:
     print(f"{e.key:32s} n={e.count:4d} shapes={str(e.input_shapes)[:110]}")
+
+# where the copies come from: python call sites of aten::copy_ / aten::clone / aten::add_ (one line per distinct site)
+import collections
+sites = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::clone", "aten::add_", "aten::add", "aten::zero_", "aten::fill_", "aten::cat", "aten::mul") and ev.stack:
+        frames = [f for f in ev.stack if "audio_visual_deepfake_detection_amd" in f or "autograd" in f]
+        sites[(ev.name, " <- ".join(s.split("/")[-1] for s in frames[:3]), str(ev.input_shapes)[:60])] += 1
+print("\ncall sites:")
+for (name, site, shp), n in sites.most_common(50):
+    print(f"{n:3d} {name:12s} {shp:60s} {site}")

@@ -28,7 +28,7 @@ SHAPES = [  # name, M, Cin, Cout, nprob, act, has_mask, residual
     ("proj 192", 1536, 256, 256, 1, 0, True, False),
     ("fc1 96", 768, 256, 1024, 1, 2, False, False),
 ]
-NCFG = 9
+NCFG = 11
 
 
 def ptr_table(ts):
