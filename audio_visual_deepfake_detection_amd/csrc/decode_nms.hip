@@ -26,17 +26,27 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
     const float* __restrict__ pmask, float* __restrict__ out_segs, float* __restrict__ out_scores,
     int32_t* __restrict__ out_pidx, int32_t* __restrict__ out_count, int P,
     float pre_nms_thresh, float duration_thresh, float min_score, float iou_thr, float voting_thr, int max_seg) {
-  __shared__ Cand key[kMaxP];
+  __shared__ Cand key[kMaxP], key2[kMaxP];      // keys by rank (key2: second buffer of the sort's LDS stages)
   __shared__ float s0[kMaxP], s1[kMaxP];        // segment of flat point p (feature-grid units)
-  __shared__ unsigned char alive[kMaxP];
+  __shared__ float r0s[kMaxP], r1s[kMaxP];      // segment of rank r
+  __shared__ unsigned long long abits[kMaxP / 64];   // survivors of the NMS, one bit per rank
   __shared__ int kept[256];
   __shared__ int n_cand, n_nms;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) { n_cand = 0; n_nms = 0; }
   __syncthreads();
 
+  // Thread (wave w, lane) owns sort positions 128 w + lane and 128 w + 64 + lane: a wave holds 128 consecutive positions in
+  // registers, so every exchange at a distance below 64 is a lane shuffle, distance 64 is the thread's own pair, and only
+  // the 10 stages at distance >= 128 go through LDS (double-buffered: one barrier each).  66 stages of dependent LDS
+  // round trips took ~40 us; this takes ~10.
+  const int lane = tid & 63, wid = tid >> 6;
+  const int pos0 = wid * 128 + lane;
+  Cand c0, c1;
   int lc = 0, ln = 0;
-  for (int p = tid; p < kMaxP; p += kNT) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int p = pos0 + h * 64;
     Cand c; c.score = -1.f; c.idx = p;
     if (p < P) {
       const float x = logits[(size_t)b * P + p];
@@ -50,50 +60,82 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
         if (!(min_score > 0.f) || prob > min_score) ++ln;
       }
     } else { s0[p] = 0.f; s1[p] = 0.f; }
-    key[p] = c;
+    if (h == 0) c0 = c; else c1 = c;
   }
   atomicAdd(&n_cand, lc);
   atomicAdd(&n_nms, ln);
-  __syncthreads();
 
   // bitonic sort of 2048 keys, rank order = `before`
+  // one compare-exchange of the key at position i with the key of its partner i ^ j in the stage (k, j)
+  auto cmpx = [&](Cand& mine, const Cand& other, int i, int k, int j) {
+    const bool first = ((i & j) == 0) == ((i & k) == 0);      // this position keeps the key that ranks ahead
+    if (first ? before(other, mine) : before(mine, other)) mine = other;
+  };
+  int buf = 0;
   for (int k = 2; k <= kMaxP; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < kMaxP; i += kNT) {
-        const int l = i ^ j;
-        if (l > i) {
-          const Cand a = key[i], c = key[l];
-          const bool up = (i & k) == 0;
-          if (up ? before(c, a) : before(a, c)) { key[i] = c; key[l] = a; }
-        }
+      if (j >= 128) {
+        Cand* kb = buf ? key2 : key;
+        kb[pos0] = c0; kb[pos0 + 64] = c1;
+        __syncthreads();
+        const Cand o0 = kb[pos0 ^ j], o1 = kb[(pos0 + 64) ^ j];
+        cmpx(c0, o0, pos0, k, j);
+        cmpx(c1, o1, pos0 + 64, k, j);
+        buf ^= 1;                                               // the next LDS stage writes the other buffer: no second barrier
+      } else if (j == 64) {
+        const Cand a = c0, c = c1;
+        cmpx(c0, c, pos0, k, j);
+        cmpx(c1, a, pos0 + 64, k, j);
+      } else {
+        Cand o0, o1;
+        o0.score = __shfl_xor(c0.score, j, 64); o0.idx = __shfl_xor(c0.idx, j, 64);
+        o1.score = __shfl_xor(c1.score, j, 64); o1.idx = __shfl_xor(c1.idx, j, 64);
+        cmpx(c0, o0, pos0, k, j);
+        cmpx(c1, o1, pos0 + 64, k, j);
       }
-      __syncthreads();
     }
   }
-
-  const int nn = n_nms;      // candidates with score > min_score occupy ranks [0, nn)
-  for (int i = tid; i < kMaxP; i += kNT) alive[i] = i < nn ? 1 : 0;
+  // ranks -> LDS: the key, and the segment of every rank (the NMS and voting loops read by rank, not through key[].idx)
+  __syncthreads();                                              // all s0 / s1 of the decode are written; the last LDS stage is read
+  key[pos0] = c0; key[pos0 + 64] = c1;
+  r0s[pos0] = s0[c0.idx]; r1s[pos0] = s1[c0.idx];
+  r0s[pos0 + 64] = s0[c1.idx]; r1s[pos0 + 64] = s1[c1.idx];
   __syncthreads();
 
-  // greedy NMS in rank order; only the first max_seg survivors are ever reported
-  // (the survivor count lives in a register of every thread -- alive[i] is read uniformly, so all threads count alike --
-  // and one barrier per kept segment orders the suppression writes before the next alive[] read)
+  const int nn = n_nms;      // candidates with score > min_score occupy ranks [0, nn)
+  const int nwords = (nn + 63) >> 6;
+  if (tid < kMaxP / 64) abits[tid] = tid * 64 + 64 <= nn ? ~0ull : (tid * 64 < nn ? (1ull << (nn - tid * 64)) - 1ull : 0ull);
+  __syncthreads();
+
+  // greedy NMS in rank order; only the first max_seg survivors are ever reported.  The survivors are a bit mask in LDS:
+  // every thread finds the next one itself (a dependent LDS read per 64 ranks skipped, not per rank), wave w owns words
+  // w, w + 16 of the mask -- it tests its 64 candidates against the kept segment and clears their bits with one ballot --
+  // and one barrier per kept segment orders the clears before the next search.  (A wave that is still searching while
+  // another already clears reads the same answer: bits at or below the segment being kept are never cleared.)
   const int cap = max_seg < 256 ? max_seg : 256;
-  int nkeep = 0;
-  for (int i = 0; i < nn; ++i) {
-    if (!alive[i]) continue;                    // uniform: LDS value read after the last barrier
+  int nkeep = 0, i = -1;
+  while (true) {
+    int w = (i + 1) >> 6;
+    unsigned long long m = w < nwords ? abits[w] & (~0ull << ((i + 1) & 63)) : 0ull;
+    while (m == 0ull && ++w < nwords) m = abits[w];
+    if (m == 0ull) break;
+    i = w * 64 + __ffsll((long long)m) - 1;
     if (tid == 0) { kept[nkeep] = i; }
-    const int pi = key[i].idx;
-    const float ix1 = s0[pi], ix2 = s1[pi];
+    const float ix1 = r0s[i], ix2 = r1s[i];
     const float ia = ix2 - ix1 + 1e-6f;
-    for (int j = i + 1 + tid; j < nn; j += kNT) {
-      if (!alive[j]) continue;
-      const int pj = key[j].idx;
-      const float xx1 = fmaxf(ix1, s0[pj]), xx2 = fminf(ix2, s1[pj]);
-      const float inter = fmaxf(0.f, xx2 - xx1);
-      const float ja = s1[pj] - s0[pj] + 1e-6f;
-      const float ovr = inter / (ia + ja - inter);
-      if (ovr >= iou_thr) alive[j] = 0;
+    for (int ww = (i >> 6) + ((wid - (i >> 6)) & 15); ww < nwords; ww += kNT / 64) {      // the words >= i / 64 this wave owns
+      const int j = ww * 64 + lane;
+      bool sup = false;
+      if (j > i && ((abits[ww] >> lane) & 1ull)) {
+        const float j0 = r0s[j], j1 = r1s[j];
+        const float xx1 = fmaxf(ix1, j0), xx2 = fminf(ix2, j1);
+        const float inter = fmaxf(0.f, xx2 - xx1);
+        const float ja = j1 - j0 + 1e-6f;
+        const float ovr = inter / (ia + ja - inter);
+        sup = ovr >= iou_thr;
+      }
+      const unsigned long long clr = __ballot(sup);
+      if (lane == 0 && clr) abits[ww] &= ~clr;
     }
     if (++nkeep >= cap) break;
     __syncthreads();
@@ -102,11 +144,10 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
   const int nk = nkeep;
   const int nc = n_cand;     // voting pool = every decoded candidate (ranks [0, nc)), nms.py:176-182
 
-  const int lane = tid & 63, wid = tid >> 6;
   for (int q = wid; q < nk; q += kNT / 64) {
     const int ri = kept[q];
     const int pi = key[ri].idx;
-    float a0 = s0[pi], a1 = s1[pi];
+    float a0 = r0s[ri], a1 = r1s[ri];
     if (voting_thr > 0.f) {
       const float la = a1 - a0;
       float wsum = 0.f;
@@ -116,9 +157,8 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
         const int j = lane + m * 64;
         sw[m] = 0.f;
         if (j < nc) {
-          const int pj = key[j].idx;
-          const float inter = fmaxf(fminf(a1, s1[pj]) - fmaxf(a0, s0[pj]), 0.f);
-          const float iou = inter / (la + (s1[pj] - s0[pj]) - inter);
+          const float inter = fmaxf(fminf(a1, r1s[j]) - fmaxf(a0, r0s[j]), 0.f);
+          const float iou = inter / (la + (r1s[j] - r0s[j]) - inter);
           if (iou >= voting_thr) { sw[m] = key[j].score * iou; wsum += sw[m]; }
         }
       }
@@ -128,10 +168,9 @@ __global__ __launch_bounds__(kNT) void decode_nms_kernel(
       for (int m = 0; m < kMaxP / 64; ++m) {
         const int j = lane + m * 64;
         if (j < nc && sw[m] != 0.f) {
-          const int pj = key[j].idx;
           const float wgt = sw[m] / wsum;
-          r0 += wgt * s0[pj];
-          r1 += wgt * s1[pj];
+          r0 += wgt * r0s[j];
+          r1 += wgt * r1s[j];
         }
       }
       a0 = wave_sum(r0);

@@ -968,3 +968,63 @@ def test_qkv_chain_input_row_map_equals_explicit_resampling(ops, shift, stride):
         assert torch.equal(a, b), "forward differs from the explicit resampling"
     for i, (a, b) in enumerate(zip(g1, g0)):
         close(a, b.cpu(), f"gradient of leaf {i}", rtol=1e-6)
+
+
+@pytest.mark.parametrize("scenario", ["trained_like", "dense_random", "few", "none"])
+def test_decode_nms_voting_dense_candidates_match_oracle(ops, scenario):
+    """Decode + hard NMS + voting on the device (one workgroup per clip, csrc/decode_nms.hip) against the oracle's
+    restatement of inference_single_video + batched_nms (av_fd_no_recon.py:760-825, libs/utils/nms.py:103-190) with
+    1512 points per clip: a trained detector's clustered candidates (long runs of suppressed ranks between survivors),
+    every point a candidate, a handful, and none.  Kept points identical, segments to fp32 rounding."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import ummaformer_ref as R
+    B, lens = 3, (768, 384, 192, 96, 48, 24)
+    P = sum(lens)
+    g = torch.Generator().manual_seed(11)
+    pts_levels = []
+    for l, T in enumerate(lens):
+        s = float(2 ** l)
+        pts_levels.append(torch.stack([torch.arange(T, dtype=torch.float32) * s, torch.zeros(T), torch.full((T,), 1e4),
+                                       torch.full((T,), s)], 1))
+    points = torch.cat(pts_levels)
+    offsets = torch.rand(B, P, 2, generator=g) * 4 + 0.5
+    if scenario == "trained_like":
+        logits = torch.full((B, P), -7.5)
+        for b in range(B):
+            for k in range(3 + b):
+                c = float(torch.randint(50, 700, (1,), generator=g))
+                w = float(torch.randint(10, 80, (1,), generator=g))
+                near = (points[:, 0] - c).abs() < w
+                logits[b, near] = torch.randn(int(near.sum()), generator=g) + 2.0
+                offsets[b, near, 0] = ((points[near, 0] - (c - w)) / points[near, 3]).clamp(min=0.1)
+                offsets[b, near, 1] = (((c + w) - points[near, 0]) / points[near, 3]).clamp(min=0.1)
+    elif scenario == "dense_random":
+        logits = torch.randn(B, P, generator=g)
+        logits[1, 100:140] = logits[1, 100]                       # ties: rank by point index
+    elif scenario == "few":
+        logits = torch.full((B, P), -9.0)
+        logits[:, [5, 6, 7, 800, 1400]] = torch.tensor([1.0, 0.5, 0.2, 3.0, 0.0])
+    else:
+        logits = torch.full((B, P), -9.0)
+    mask = torch.ones(B, P)
+    mask[2, 700:768] = 0
+    cfg = dict(num_classes=1, pre_nms_thresh=0.001, pre_nms_topk=5000, duration_thresh=0.05, nms_method="hard",
+               multiclass_nms=False, min_score=0.001, iou_threshold=0.75, max_seg_num=100, voting_thresh=0.75)
+    segs, scores, pidx, count = ops.decode_nms(points.to(dev()), logits.to(dev()), offsets.to(dev()), mask.to(dev()),
+                                               cfg["pre_nms_thresh"], cfg["duration_thresh"], cfg["min_score"],
+                                               cfg["iou_threshold"], cfg["voting_thresh"], cfg["max_seg_num"])
+    torch.cuda.synchronize()
+    for b in range(B):
+        lg, of, mk, o = [], [], [], 0
+        for T in lens:
+            lg.append(logits[b, o:o + T, None]); of.append(offsets[b, o:o + T]); mk.append(mask[b, o:o + T]); o += T
+        s_, c_, l_, p_ = R.decode_single(cfg, pts_levels, mk, lg, of)
+        rs, rc, _, rk = R.batched_nms_ref(cfg, s_, c_, l_)
+        n = int(count[b])
+        assert n == rs.shape[0], f"{scenario} clip {b}: {n} segments kept, oracle {rs.shape[0]}"
+        if n == 0:
+            continue
+        assert torch.equal(pidx[b, :n].cpu().long(), p_[rk]), f"{scenario} clip {b}: kept points differ"
+        close(scores[b, :n], rc, f"{scenario} clip {b}: scores", rtol=1e-6)      # expf vs torch.sigmoid: an ulp
+        close(segs[b, :n], rs, f"{scenario} clip {b}: voted segments", rtol=5e-6)
