@@ -112,6 +112,7 @@ SIGNATURES = {
     "avdf_chain_bwd_map": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, P]),
     "avdf_chain_bwd_folds": (I, [I, I]),
     "avdf_reduce_segments": (I, [P, I, I, I, P, P, P, P, I, P]),
+    "avdf_reduce_segments_batched": (I, [I, P, P, P, P, P, P, P, P, P]),
     "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "avdf_conv3d_mode": (I, [I]),
     "avdf_video_prep": (I, [P, P, I, I, I, I, I, P]),

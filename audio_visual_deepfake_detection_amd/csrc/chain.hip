@@ -14,6 +14,7 @@
 //           of a workgroup go to a workspace row that avdf_reduce_segments folds (no float atomics).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -331,6 +332,71 @@ __global__ __launch_bounds__(1024) void reduce_segments_kernel(const float* __re
   }
 }
 
+// Several reduce_segments jobs in ONE launch (the engine path flushes the parameter partials of all chain backward
+// launches of a backward phase together: a dependent tiny launch costs 2.4 us).  Compact per-job
+// descriptors so that kBatchJobs of them fit the kernel-argument segment.
+constexpr int kBatchJobs = 10;
+struct SegJob {
+  const float* ws;
+  float* dst[kMaxSeg];
+  int nrow, stride;
+  unsigned short first[kMaxSeg + 1];     // prefix sum of the segment lengths (<= row stride <= 65535)
+  unsigned short src[kMaxSeg][3];
+  unsigned char nsrc[kMaxSeg];
+  unsigned char nseg;
+};
+struct SegBatch {
+  SegJob job[kBatchJobs];
+  int cb_first[kBatchJobs + 1];          // prefix sum of the jobs' 64-column blocks
+  int njobs;
+};
+// accumulating only: dst[s][i] += ...; the rows of a job are split over blockIdx.y, partial sums meet in dst by atomics.
+// A workgroup folds 64 columns: a lane owns one float4 column group and one of four row phases of its wave, four rows in
+// flight per lane (the one-float-per-lane, one-row-at-a-time walk of reduce_segments_kernel keeps 256 bytes in flight per
+// wave and reads at ~0.8 TB/s).  Segment starts, lengths and source offsets are multiples of 4 floats (host-checked).
+__global__ __launch_bounds__(1024) void reduce_segments_batch_kernel(SegBatch bt) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6, cg = lane & 15, rs = lane >> 4;
+  int j = 0;
+  while (j + 1 < bt.njobs && (int)blockIdx.x >= bt.cb_first[j + 1]) ++j;
+  const SegJob& jb = bt.job[j];
+  const int col = ((int)blockIdx.x - bt.cb_first[j]) * 64 + cg * 4;
+  const int total = jb.first[jb.nseg];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < total) {
+    int s = 0;
+    while (col >= jb.first[s + 1]) ++s;
+    const int i = col - jb.first[s];
+    const int chunk = (jb.nrow + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * chunk, r1 = min(jb.nrow, r0 + chunk);
+    const size_t stride = (size_t)jb.stride;
+    for (int q = 0; q < jb.nsrc[s]; ++q) {
+      const float* p = jb.ws + jb.src[s][q] + i;
+      int r = r0 + ph * 4 + rs;
+      for (; r + 192 < r1; r += 256) {                // rows r, r+64, r+128, r+192 of this lane: four loads in flight
+        const float4 v0 = ld4(p + r * stride), v1 = ld4(p + (r + 64) * stride), v2 = ld4(p + (r + 128) * stride),
+                     v3 = ld4(p + (r + 192) * stride);
+        acc = add4(acc, add4(add4(v0, v1), add4(v2, v3)));
+      }
+      for (; r < r1; r += 64) acc = add4(acc, ld4(p + r * stride));
+    }
+  }
+  // the four row phases of a wave meet by shuffles, the sixteen waves through LDS
+  acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64); acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+  acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64); acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+  if (rs == 0) { red[ph][cg * 4] = acc.x; red[ph][cg * 4 + 1] = acc.y; red[ph][cg * 4 + 2] = acc.z; red[ph][cg * 4 + 3] = acc.w; }
+  __syncthreads();
+  const int c1 = ((int)blockIdx.x - bt.cb_first[j]) * 64 + lane;
+  if (ph == 0 && c1 < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][lane];
+    int s = 0;
+    while (c1 >= jb.first[s + 1]) ++s;
+    atomicAdd(jb.dst[s] + (c1 - jb.first[s]), t);
+  }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 constexpr int kTile = 32, kWaves = 8;
 // backward: 16-token tiles -> twice the workgroups, 76 KB of LDS each (2 per CU): the three branches of a tile are
@@ -528,5 +594,47 @@ extern "C" int avdf_reduce_segments(const float* ws, int nrow, int row_stride, i
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(cdiv(sa.first[nseg], 64), ysplit), dim3(1024), 0, (hipStream_t)stream, ws, nrow,
                      row_stride, sa, nseg, accumulate);
   AVDF_CHECK_LAUNCH("reduce_segments");
+  return AVDF_OK;
+}
+
+// njobs accumulating reduce_segments jobs in ceil(njobs / 10) launches.  Job j: workspace ws[j] of nrow[j] rows x stride[j]
+// floats, nseg[j] segments; the segment tables of all jobs are concatenated: dst / len / nsrc one entry per segment,
+// src_off three.  Every destination is ADDED to (float atomics; the rows of a job are split four ways over the grid).
+extern "C" int avdf_reduce_segments_batched(int njobs, const float* const* ws, const int* nrow, const int* stride, const int* nseg,
+                                            float* const* dst, const int* len, const int* nsrc, const int* src_off, void* stream) {
+  AVDF_REQUIRE(njobs > 0 && ws && nrow && stride && nseg && dst && len && nsrc && src_off, "reduce_segments_batched: bad args");
+  static_assert(sizeof(SegBatch) <= 4000, "the job descriptors must fit the kernel-argument segment");
+  int seg0 = 0;
+  for (int j0 = 0; j0 < njobs; j0 += kBatchJobs) {
+    SegBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.njobs = njobs - j0 < kBatchJobs ? njobs - j0 : kBatchJobs;
+    bt.cb_first[0] = 0;
+    for (int q = 0; q < bt.njobs; ++q) {
+      const int j = j0 + q;
+      SegJob& jb = bt.job[q];
+      AVDF_REQUIRE(ws[j] && aligned16(ws[j]) && nrow[j] > 0 && stride[j] > 0 && stride[j] % 4 == 0 && stride[j] <= 65535 && nseg[j] > 0 && nseg[j] <= kMaxSeg,
+                   "reduce_segments_batched: bad job %d", j);
+      jb.ws = ws[j]; jb.nrow = nrow[j]; jb.stride = stride[j]; jb.nseg = (unsigned char)nseg[j];
+      int first = 0;
+      for (int s = 0; s < nseg[j]; ++s, ++seg0) {
+        AVDF_REQUIRE(dst[seg0] && len[seg0] > 0 && len[seg0] % 4 == 0 && nsrc[seg0] >= 1 && nsrc[seg0] <= 3,
+                     "reduce_segments_batched: bad segment %d of job %d (lengths are multiples of 4)", s, j);
+        jb.dst[s] = dst[seg0]; jb.nsrc[s] = (unsigned char)nsrc[seg0]; jb.first[s] = (unsigned short)first;
+        for (int k = 0; k < 3; ++k) {
+          const int o = src_off[seg0 * 3 + k];
+          AVDF_REQUIRE(k >= nsrc[seg0] || (o >= 0 && o % 4 == 0 && o + len[seg0] <= stride[j]), "reduce_segments_batched: source out of the row");
+          jb.src[s][k] = (unsigned short)(k < nsrc[seg0] ? o : 0);
+        }
+        first += len[seg0];
+        AVDF_REQUIRE(first <= 65535, "reduce_segments_batched: job %d too wide", j);
+      }
+      for (int s = nseg[j]; s <= kMaxSeg; ++s) jb.first[s] = (unsigned short)first;
+      bt.cb_first[q + 1] = bt.cb_first[q] + cdiv(first, 64);
+    }
+    for (int q = bt.njobs; q < kBatchJobs; ++q) bt.cb_first[q + 1] = bt.cb_first[bt.njobs];
+    hipLaunchKernelGGL(reduce_segments_batch_kernel, dim3(bt.cb_first[bt.njobs], 4), dim3(1024), 0, (hipStream_t)stream, bt);
+    AVDF_CHECK_LAUNCH("reduce_segments_batched");
+  }
   return AVDF_OK;
 }

@@ -294,11 +294,13 @@ class TrainStep:
 
     def _stage_bwd(self, i):
         ops.WGRAD_SIDE_STREAM = self.wgrad_side
+        ops.begin_deferred_reductions()          # the chains' parameter partials of this phase are folded in one go
         try:
             self._run_phase(self._phases[i], retain=self.use_graph)
         finally:
             ops.WGRAD_SIDE_STREAM = False
             ops.wgrad_join()
+            ops.flush_deferred_reductions()
 
     def _stage_c(self):
         st = torch.cuda.current_stream().cuda_stream

@@ -144,6 +144,35 @@ def _ws(n, like):
     return torch.empty(max(int(n), 1), dtype=torch.float32, device=like.device)
 
 
+# Accumulating segmented reductions (parameter partials of the chain backward kernels) queued while a backward phase of
+# engine.TrainStep runs, then folded in ceil(n / 10) launches instead of one dependent tiny launch per chain.
+_DEFERRED = None
+DEFER_REDUCTIONS = _os.environ.get("AVDF_DEFER_REDUCTIONS", "1") != "0"
+
+
+def begin_deferred_reductions():
+    global _DEFERRED
+    if DEFER_REDUCTIONS:
+        _DEFERRED = []
+
+
+def flush_deferred_reductions():
+    """Launch the queued jobs on the current stream (the stream the backward pass ran on) and stop queueing."""
+    global _DEFERRED
+    jobs, _DEFERRED = _DEFERRED, None
+    if not jobs:
+        return
+    n = len(jobs)
+    dst = [d for j in jobs for d in j[3]]
+    lens = [v for j in jobs for v in j[4]]
+    srcs = [s_ for j in jobs for s_ in j[5]]
+    ci = lambda vals: (ctypes.c_int * len(vals))(*vals)
+    check(lib.avdf_reduce_segments_batched(n, _ptr_table([j[0] for j in jobs]), ci([j[1] for j in jobs]), ci([j[2] for j in jobs]),
+                                           ci([len(j[3]) for j in jobs]), _ptr_table(dst), ci(lens), ci([len(s_) for s_ in srcs]),
+                                           ci([(s_ + [0, 0, 0])[k] for s_ in srcs for k in range(3)]), _stream()),
+          "reduce_segments_batched")
+
+
 def _main_grad(t):
     """Flat-buffer gradient view attached by engine.TrainStep (`param.main_grad`): when present, the
     backward kernels ACCUMULATE straight into it (accumulate=1) and autograd receives None, so there
@@ -840,8 +869,12 @@ class QkvChainFn(torch.autograd.Function):
         lens = (ctypes.c_int * nseg)(*seg_len)
         nsrc = (ctypes.c_int * nseg)(*[len(s_) for s_ in seg_src])
         offs = (ctypes.c_int * (nseg * 3))(*[(s_ + [0, 0, 0])[j] for s_ in seg_src for j in range(3)])
-        check(lib.avdf_reduce_segments(_p(wsb), lib.avdf_chain_bwd_rows(B, Tin), 21 * C, nseg, _ptr_table(seg_dst), lens, nsrc,
-                                       offs, 1 if acc else 0, _stream()), "reduce_segments")
+        if acc and _DEFERRED is not None:
+            # engine path: folded together with the other chains of this backward phase (flush_deferred_reductions)
+            _DEFERRED.append((wsb, int(lib.avdf_chain_bwd_rows(B, Tin)), 21 * C, seg_dst, seg_len, seg_src))
+        else:
+            check(lib.avdf_reduce_segments(_p(wsb), lib.avdf_chain_bwd_rows(B, Tin), 21 * C, nseg, _ptr_table(seg_dst), lens, nsrc,
+                                           offs, 1 if acc else 0, _stream()), "reduce_segments")
         g = grads
         return (dx[0], dx[1], dx[2], g[0][0], g[1][0], g[0][1], g[1][1], g[0][2], g[1][2], g[2][0], g[2][1], g[2][2],
                 g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None, None, None)

@@ -439,6 +439,11 @@ int avdf_chain_bwd_map(const float* const* dy, const float* const* u, const floa
  * i < len[s]; up to 16 segments per launch (host arrays).                                                   */
 int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,
                          const int* nsrc, const int* src_off, int accumulate, void* stream);
+/* njobs ACCUMULATING avdf_reduce_segments jobs in ceil(njobs / 10) launches (the engine flushes the parameter partials of
+ * every LN -> dw-conv -> LN chain backward of a backward phase together).  ws / nrow / stride / nseg: one entry per job;
+ * dst / len / nsrc (one entry per segment) and src_off (three) are the jobs' segment tables concatenated.            */
+int avdf_reduce_segments_batched(int njobs, const float* const* ws, const int* nrow, const int* stride, const int* nseg,
+                                 float* const* dst, const int* len, const int* nsrc, const int* src_off, void* stream);
 
 /* ---- LAV-DF visual encoder (C3D; frozen extractor, forward only) -------------------------------------
  * Reference: video_feature/aligned_video/model/video_encoder.py:27-62 (7x Conv3d 3x3x3 pad 1 + LeakyReLU,

@@ -1028,3 +1028,36 @@ def test_decode_nms_voting_dense_candidates_match_oracle(ops, scenario):
         assert torch.equal(pidx[b, :n].cpu().long(), p_[rk]), f"{scenario} clip {b}: kept points differ"
         close(scores[b, :n], rc, f"{scenario} clip {b}: scores", rtol=1e-6)      # expf vs torch.sigmoid: an ulp
         close(segs[b, :n], rs, f"{scenario} clip {b}: voted segments", rtol=5e-6)
+
+
+def test_reduce_segments_batched_matches_torch(ops):
+    """avdf_reduce_segments_batched (the engine's one-launch fold of the parameter partials of every chain backward of a
+    backward phase): 13 jobs (two launches) of different row counts, segments with one to three sources, ADDED to the
+    destinations, against float64."""
+    import ctypes
+    from audio_visual_deepfake_detection_amd._lib import lib, check
+    g = torch.Generator().manual_seed(5)
+    C = 64
+    jobs, refs, keep = [], [], []
+    for j in range(13):
+        nrow, stride = int(torch.randint(1, 700, (1,), generator=g)), 21 * C
+        ws = torch.randn(nrow, stride, generator=g)
+        segs = [(C, [0]), (C, [C, 8 * C]), (3 * C, [2 * C]), (C, [5 * C, 12 * C, 19 * C]), (4, [20 * C])][: 2 + j % 4]
+        dst0 = [torch.randn(n, generator=g) for n, _ in segs]
+        ref = [d.double() + sum(ws[:, o:o + n].double().sum(0) for o in src) for d, (n, src) in zip(dst0, segs)]
+        wsd, dstd = g32(ws), [g32(d) for d in dst0]
+        keep.append((wsd, dstd))
+        jobs.append((wsd, nrow, stride, dstd, [n for n, _ in segs], [src for _, src in segs]))
+        refs.append(ref)
+    ci = lambda v: (ctypes.c_int * len(v))(*v)
+    tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    srcs = [s_ for j in jobs for s_ in j[5]]
+    check(lib.avdf_reduce_segments_batched(len(jobs), tab([j[0] for j in jobs]), ci([j[1] for j in jobs]), ci([j[2] for j in jobs]),
+                                           ci([len(j[3]) for j in jobs]), tab([d for j in jobs for d in j[3]]),
+                                           ci([n for j in jobs for n in j[4]]), ci([len(s_) for s_ in srcs]),
+                                           ci([(s_ + [0, 0, 0])[k] for s_ in srcs for k in range(3)]),
+                                           torch.cuda.current_stream().cuda_stream), "reduce_segments_batched")
+    torch.cuda.synchronize()
+    for j, (job, ref) in enumerate(zip(jobs, refs)):
+        for s_, (d, r) in enumerate(zip(job[3], ref)):
+            close(d, r, f"job {j} segment {s_}", rtol=1e-5)
