@@ -26,12 +26,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   const int row = blockIdx.x * 4 + wid;
   if (row >= M) return;
   const float* xr = x + (size_t)row * C;
-  float4 v[NV];
+  float4 v[NV], gv[NV], bv[NV];                        // gamma / beta / row factors fetched with the row, not after its reductions
+  const float mk = (pe && mask) ? mask[row] : 1.0f;
+  const float rs = rowscale ? rowscale[row] : 1.0f;
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = (j * 64 + lane) * 4;
-    if (c < C) { v[j] = ld4(xr + c); s += v[j].x + v[j].y + v[j].z + v[j].w; }
+    gv[j] = make_float4(1.f, 1.f, 1.f, 1.f); bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      v[j] = ld4(xr + c);
+      if (gamma) { gv[j] = ld4(gamma + c); bv[j] = ld4(beta + c); }
+      s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
     else v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float mean = wave_sum(s) / (float)C;
@@ -46,15 +53,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
   if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
-  const float mk = (pe && mask) ? mask[row] : 1.0f;
-  const float rs = rowscale ? rowscale[row] : 1.0f;
   const int t = pe ? row % T : 0;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = (j * 64 + lane) * 4;
     if (c < C) {
-      float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gamma) { g = ld4(gamma + c); bb = ld4(beta + c); }
+      const float4 g = gv[j], bb = bv[j];
       float4 o;
       o.x = (v[j].x - mean) * rstd * g.x + bb.x;
       o.y = (v[j].y - mean) * rstd * g.y + bb.y;
@@ -86,20 +90,41 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
   float4 ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) { ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j]; }
-  for (int row = blockIdx.x * NW + wid; row < M; row += gridDim.x * NW) {
-    const float mean = mean_i[row], rstd = rstd_i[row];
-    const float rs = rowscale ? rowscale[row] : 1.0f;
+  // (a wave walks M / (128 x 16) rows one after the other: the next row's loads are in flight while this one is reduced)
+  float4 gm[NV], bt[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    gm[j] = make_float4(1.f, 1.f, 1.f, 1.f); bt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gamma && c < C) { gm[j] = ld4(gamma + c); bt[j] = ld4(beta + c); }
+  }
+  struct Row { float4 xv[NV], d[NV]; float mean, rstd, rs; };
+  auto load_row = [&](int row, Row& w) {
+    w.mean = mean_i[row]; w.rstd = rstd_i[row];
+    w.rs = rowscale ? rowscale[row] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      w.xv[j] = make_float4(0.f, 0.f, 0.f, 0.f); w.d[j] = w.xv[j];
+      if (c < C) { w.xv[j] = ld4(x + (size_t)row * C + c); w.d[j] = ld4(dy + (size_t)row * C + c); }
+    }
+  };
+  const int step = gridDim.x * NW;
+  int row = blockIdx.x * NW + wid;
+  Row cur, nxt;
+  if (row < M) load_row(row, cur);
+  for (; row < M; row += step) {
+    if (row + step < M) load_row(row + step, nxt);
+    const float mean = cur.mean, rstd = cur.rstd, rs = cur.rs;
     float4 xh[NV], gy[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (j * 64 + lane) * 4;
       if (c < C) {
-        const float4 xv = ld4(x + (size_t)row * C + c);
-        float4 d = ld4(dy + (size_t)row * C + c);
+        const float4 xv = cur.xv[j], g = gm[j], bb = bt[j];
+        float4 d = cur.d[j];
         d.x *= rs; d.y *= rs; d.z *= rs; d.w *= rs;
-        float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gamma) { g = ld4(gamma + c); bb = ld4(beta + c); }
         float4 h;
         h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
         if (relu) {
@@ -129,6 +154,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_kernel(
         *reinterpret_cast<float4*>(dx + (size_t)row * C + c) = o;
       }
     }
+    cur = nxt;
   }
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -303,13 +329,14 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
   const float fa = ma ? ma[row] : 1.f;
   float fr = keep ? keep[row / T] : 1.f;
   if (mr) fr *= mr[row];
-  float4 v[NV];
+  float4 v[NV], gv[NV], bv[NV];                        // gamma / beta fetched with the row, not after its reductions
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = (j * 64 + lane) * 4;
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f); gv[j] = v[j]; bv[j] = v[j];
     if (c < C) {
+      gv[j] = ld4(gamma + c); bv[j] = ld4(beta + c);
       const float4 av = ld4(a + (size_t)row * C + c), rv = ld4(r + (size_t)row * C + c), sc = ld4(scale + c);
       v[j].x = av.x * fa + rv.x * sc.x * fr; v[j].y = av.y * fa + rv.y * sc.y * fr;
       v[j].z = av.z * fa + rv.z * sc.z * fr; v[j].w = av.w * fa + rv.w * sc.w * fr;
@@ -333,7 +360,7 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(
   for (int j = 0; j < NV; ++j) {
     const int c = (j * 64 + lane) * 4;
     if (c < C) {
-      const float4 g = ld4(gamma + c), bb = ld4(beta + c);
+      const float4 g = gv[j], bb = bv[j];
       float4 o;
       o.x = (v[j].x - mean) * rstd * g.x + bb.x; o.y = (v[j].y - mean) * rstd * g.y + bb.y;
       o.z = (v[j].z - mean) * rstd * g.z + bb.z; o.w = (v[j].w - mean) * rstd * g.w + bb.w;
@@ -358,30 +385,56 @@ __global__ __launch_bounds__(64 * NW) void residual_ln_bwd_kernel(
   float4 as[NV], ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) { as[j] = make_float4(0.f, 0.f, 0.f, 0.f); ag[j] = as[j]; ab[j] = as[j]; }
-  for (int row = blockIdx.x * NW + wid; row < M; row += gridDim.x * NW) {
-    const float mean = mean_i[row], rstd = rstd_i[row];
-    const float fa = ma ? ma[row] : 1.f;
-    float fr = keep ? keep[row / T] : 1.f;
-    if (mr) fr *= mr[row];
+  float4 gm[NV], scv[NV];                               // per-column constants of this lane
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    gm[j] = make_float4(0.f, 0.f, 0.f, 0.f); scv[j] = gm[j];
+    if (c < C) { gm[j] = ld4(gamma + c); scv[j] = ld4(scale + c); }
+  }
+  // A wave walks only M / (128 x 16) rows one after the other, so the kernel's duration IS its rows' memory round trips:
+  // every load of a row goes out before the first reduction (one round trip per row, not two), and the loads of the NEXT
+  // row are in flight while this one is reduced.
+  struct Row { float4 ov[NV], d[NV], ev[NV], rv[NV]; float mean, rstd, fa, fr; };
+  auto load_row = [&](int row, Row& w) {
+    w.mean = mean_i[row]; w.rstd = rstd_i[row];
+    w.fa = ma ? ma[row] : 1.f;
+    w.fr = keep ? keep[row / T] : 1.f;
+    if (mr) w.fr *= mr[row];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      w.ov[j] = make_float4(0.f, 0.f, 0.f, 0.f); w.d[j] = w.ov[j]; w.ev[j] = w.ov[j]; w.rv[j] = w.ov[j];
+      if (c < C) {
+        w.ov[j] = ld4(out + (size_t)row * C + c);
+        w.d[j] = ld4(dh + (size_t)row * C + c);
+        if (dout) w.ev[j] = ld4(dout + (size_t)row * C + c);
+        w.rv[j] = ld4(r + (size_t)row * C + c);
+      }
+    }
+  };
+  const int step = gridDim.x * NW;
+  int row = blockIdx.x * NW + wid;
+  Row cur, nxt;
+  if (row < M) load_row(row, cur);
+  for (; row < M; row += step) {
+    if (row + step < M) load_row(row + step, nxt);
+    const float mean = cur.mean, rstd = cur.rstd, fa = cur.fa, fr = cur.fr;
     float4 xh[NV], gy[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int c = (j * 64 + lane) * 4;
-      xh[j] = make_float4(0.f, 0.f, 0.f, 0.f); gy[j] = xh[j];
-      if (c < C) {
-        const float4 ov = ld4(out + (size_t)row * C + c);
-        float4 d = ld4(dh + (size_t)row * C + c);
-        const float4 g = ld4(gamma + c);
-        float4 hh;
-        hh.x = (ov.x - mean) * rstd; hh.y = (ov.y - mean) * rstd; hh.z = (ov.z - mean) * rstd; hh.w = (ov.w - mean) * rstd;
-        ag[j].x += d.x * hh.x; ag[j].y += d.y * hh.y; ag[j].z += d.z * hh.z; ag[j].w += d.w * hh.w;
-        ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
-        d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;
-        s1 += d.x + d.y + d.z + d.w;
-        s2 += d.x * hh.x + d.y * hh.y + d.z * hh.z + d.w * hh.w;
-        xh[j] = hh; gy[j] = d;
-      }
+      const float4 ov = cur.ov[j], g = gm[j];
+      float4 d = cur.d[j];
+      float4 hh;
+      hh.x = (ov.x - mean) * rstd; hh.y = (ov.y - mean) * rstd; hh.z = (ov.z - mean) * rstd; hh.w = (ov.w - mean) * rstd;
+      if ((j * 64 + lane) * 4 >= C) hh = make_float4(0.f, 0.f, 0.f, 0.f);
+      ag[j].x += d.x * hh.x; ag[j].y += d.y * hh.y; ag[j].z += d.z * hh.z; ag[j].w += d.w * hh.w;
+      ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+      d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;
+      s1 += d.x + d.y + d.z + d.w;
+      s2 += d.x * hh.x + d.y * hh.y + d.z * hh.z + d.w * hh.w;
+      xh[j] = hh; gy[j] = d;
     }
     const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
 #pragma unroll
@@ -391,14 +444,15 @@ __global__ __launch_bounds__(64 * NW) void residual_ln_bwd_kernel(
         float4 t;
         t.x = rstd * (gy[j].x - m1 - xh[j].x * m2); t.y = rstd * (gy[j].y - m1 - xh[j].y * m2);
         t.z = rstd * (gy[j].z - m1 - xh[j].z * m2); t.w = rstd * (gy[j].w - m1 - xh[j].w * m2);
-        if (dout) { const float4 e = ld4(dout + (size_t)row * C + c); t.x += e.x; t.y += e.y; t.z += e.z; t.w += e.w; }
-        const float4 rv = ld4(r + (size_t)row * C + c), sc = ld4(scale + c);
+        t.x += cur.ev[j].x; t.y += cur.ev[j].y; t.z += cur.ev[j].z; t.w += cur.ev[j].w;
+        const float4 sc = scv[j], rv = cur.rv[j];
         as[j].x += t.x * rv.x * fr; as[j].y += t.y * rv.y * fr; as[j].z += t.z * rv.z * fr; as[j].w += t.w * rv.w * fr;
         if (da) *reinterpret_cast<float4*>(da + (size_t)row * C + c) = make_float4(t.x * fa, t.y * fa, t.z * fa, t.w * fa);
         if (dr) *reinterpret_cast<float4*>(dr + (size_t)row * C + c) =
             make_float4(t.x * sc.x * fr, t.y * sc.y * fr, t.z * sc.z * fr, t.w * sc.w * fr);
       }
     }
+    cur = nxt;
   }
 #pragma unroll
   for (int j = 0; j < NV; ++j) {

@@ -194,15 +194,28 @@ __global__ __launch_bounds__(kFusedThreads) void affine_residual_bwd_fused_kerne
   const float4 sc = ld4(scale + c);
   float4 ds = f4(0.f);
   const long total = (long)B * T * C4;
-  for (long i = (long)blockIdx.x * kFusedThreads + threadIdx.x; i < total; i += (long)gridDim.x * kFusedThreads) {
+  // a thread walks total / (128 x 1024) elements one after the other: the loads of the next element are in flight while
+  // this one is stored (the kernel's duration is its elements' memory round trips)
+  const long step = (long)gridDim.x * kFusedThreads;
+  long i = (long)blockIdx.x * kFusedThreads + threadIdx.x;
+  float4 g = f4(0.f), rr = f4(0.f), gn = f4(0.f), rn = f4(0.f);
+  float fa = 1.f, f = 1.f, fan = 1.f, fn = 1.f;
+  auto fetch = [&](long e, float4& g_, float4& r_, float& fa_, float& f_) {
+    const long bt = e / C4;
+    g_ = ld4(dout + bt * C + c);
+    r_ = ld4(r + bt * C + c);
+    fa_ = ma ? ma[bt] : 1.f;
+    f_ = keep ? keep[bt / T] : 1.f;
+    if (mr) f_ *= mr[bt];
+  };
+  if (i < total) fetch(i, g, rr, fa, f);
+  for (; i < total; i += step) {
+    if (i + step < total) fetch(i + step, gn, rn, fan, fn);
     const long bt = i / C4;
-    const long b = bt / T;
-    const float4 g = ld4(dout + bt * C + c);
-    if (da) st4(da + bt * C + c, ma ? scl4(g, ma[bt]) : g);
-    float f = keep ? keep[b] : 1.f;
-    if (mr) f *= mr[bt];
+    if (da) st4(da + bt * C + c, ma ? scl4(g, fa) : g);
     if (dr) st4(dr + bt * C + c, scl4(mul4(g, sc), f));
-    ds = add4(ds, scl4(mul4(g, ld4(r + bt * C + c)), f));
+    ds = add4(ds, scl4(mul4(g, rr), f));
+    g = gn; rr = rn; fa = fan; f = fn;
   }
   float* d = red + threadIdx.x * 4;
   d[0] = ds.x; d[1] = ds.y; d[2] = ds.z; d[3] = ds.w;
