@@ -58,6 +58,7 @@ SIGNATURES = {
     "avdf_maxpool3s2_bwd": (I, [P, P, P, I, I, I, P]),
     "avdf_affine_residual_fwd": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "avdf_affine_residual_bwd_ws": (L, [I, I, I]),
+    "avdf_affine_residual_bwd_rows": (I, [I, I, I]),
     "avdf_affine_residual_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "avdf_upsample_fwd": (I, [P, P, I, I, I, I, P]),
     "avdf_upsample_bwd": (I, [P, P, I, I, I, I, P]),

@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int kLnMaxV = 8;            // float4 per lane -> C <= 2048
-constexpr int kLnBwdBlocks = 128;
+constexpr int kLnBwdBlocks = 256;     // 128 while the workgroups added their partials by float atomics; rows + deferred fold: 843 -> 846 clips/s
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -512,7 +512,9 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
   AVDF_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && (!gamma || (aligned16(gamma) && aligned16(beta))), "layernorm_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
   const int G = ln_bwd_blocks(M, C);
-  const bool atomic = accumulate && dgamma && dbeta;
+  // accumulate: 0 overwrite, 1 add by float atomics inside the kernel, 2 leave the workgroups' rows [G][dgamma | dbeta] in ws
+  // for the caller to ADD (avdf_reduce_segments_batched; G = avdf_layernorm_bwd_ws / 2C)
+  const bool atomic = accumulate == 1 && dgamma && dbeta;
   float* dga = atomic ? dgamma : nullptr;
   float* dba = atomic ? dbeta : nullptr;
 #define LN_BWD(NV_, NW_) hipLaunchKernelGGL((ln_bwd_kernel<NV_, NW_>), dim3(G), dim3(64 * NW_),                 \
@@ -521,7 +523,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
   if (C <= 256) LN_BWD(1, 16); else if (C <= 512) LN_BWD(2, 8); else if (C <= 1024) LN_BWD(4, 4); else LN_BWD(8, 4);
 #undef LN_BWD
   AVDF_CHECK_LAUNCH("layernorm_bwd");
-  if (dgamma && !atomic) {
+  if (dgamma && !atomic && accumulate != 2) {
     AVDF_REQUIRE(dbeta, "layernorm_bwd: dgamma and dbeta must both be requested");
     int rc = avdf_reduce_slabs2(ws, dgamma, dbeta, G, 2 * (int64_t)C, C, accumulate, st);
     if (rc) return rc;
@@ -592,16 +594,18 @@ extern "C" int avdf_residual_ln_bwd(const float* dout, const float* dh, const fl
                    aligned16(da) && aligned16(dr), "residual_ln_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
   const int M = B * T, G = ln_bwd_blocks(M, C);
-  float* sa = accumulate ? dscale : nullptr;
-  float* ga = accumulate ? dgamma : nullptr;
-  float* ba = accumulate ? dbeta : nullptr;
+  // accumulate: 0 overwrite (workspace rows + reduction), 1 add by float atomics inside the kernel, 2 workspace rows only --
+  // [rows = ws floats / 3C][dscale | dgamma | dbeta], to be ADDED by the caller (avdf_reduce_segments_batched)
+  float* sa = accumulate == 1 ? dscale : nullptr;
+  float* ga = accumulate == 1 ? dgamma : nullptr;
+  float* ba = accumulate == 1 ? dbeta : nullptr;
 #define RLN_BWD(NV_, NW_) hipLaunchKernelGGL((residual_ln_bwd_kernel<NV_, NW_>), dim3(G), dim3(64 * NW_),              \
                                             (size_t)3 * NW_ * C * sizeof(float), st, dout, dh, out, mean, rstd, gamma,  \
                                             ma, r, mr, scale, keep, da, dr, ws, sa, ga, ba, M, T, C)
   if (C <= 256) RLN_BWD(1, 16); else if (C <= 512) RLN_BWD(2, 8); else if (C <= 1024) RLN_BWD(4, 4); else RLN_BWD(8, 4);
 #undef RLN_BWD
   AVDF_CHECK_LAUNCH("residual_ln_bwd");
-  if (!accumulate) {                                                      // ws rows: [dscale | dgamma | dbeta]
+  if (accumulate == 0) {                                                  // ws rows: [dscale | dgamma | dbeta]
     float* dst[3] = {dscale, dgamma, dbeta};
     const int len[3] = {C, C, C}, nsrc[3] = {1, 1, 1};
     const int off[9] = {0, 0, 0, C, 0, 0, 2 * C, 0, 0};

@@ -24,7 +24,8 @@ static int fused_blocks(long elems4) {
   static const char* e = getenv("AVDF_FUSED_BLOCKS");      // tuning override for tools/pw_bench.py
   const long cap = e ? atoi(e) : 128;
   const long g = (elems4 + kFusedThreads - 1) / kFusedThreads;
-  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+  const long c2 = cap > 512 ? 512 : cap;                    // workspaces of the row modes hold at most 512 rows
+  return (int)(g < 1 ? 1 : (g > c2 ? c2 : g));
 }
 
 // weights of 4 consecutive channels: w[c..c+3][0..2] = 12 contiguous floats -> per-tap float4
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kFusedThreads) void dwconv_bwd_fused_kernel(const f
 __global__ __launch_bounds__(kFusedThreads) void affine_residual_bwd_fused_kernel(
     const float* __restrict__ dout, const float* __restrict__ ma, const float* __restrict__ r,
     const float* __restrict__ mr, const float* __restrict__ scale, const float* __restrict__ keep,
-    float* __restrict__ da, float* __restrict__ dr, float* __restrict__ dscale, int B, int T, int C) {
+    float* __restrict__ da, float* __restrict__ dr, float* __restrict__ dscale, float* __restrict__ ws_rows, int B, int T, int C) {
   __shared__ float red[kFusedThreads * 4];
   const int C4 = C >> 2;
   const int c = (int)(((long)blockIdx.x * kFusedThreads + threadIdx.x) % C4) * 4;
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(kFusedThreads) void affine_residual_bwd_fused_kerne
     float s_ = 0.f;
     for (int q = e; q < kFusedThreads * 4; q += per) s_ += red[q];
     const int quad = ((blockIdx.x * kFusedThreads) % C4 + e / 4) % C4;
-    atomicAdd(dscale + quad * 4 + (e % 4), s_);
+    if (ws_rows) ws_rows[(size_t)blockIdx.x * C + quad * 4 + (e % 4)] = s_;      // a row per workgroup, added by the caller
+    else atomicAdd(dscale + quad * 4 + (e % 4), s_);
   }
 }
 
@@ -514,7 +516,12 @@ extern "C" int avdf_affine_residual_fwd(const float* a, const float* ma, const f
   return AVDF_OK;
 }
 
-extern "C" int64_t avdf_affine_residual_bwd_ws(int B, int T, int C) { (void)B; (void)T; return (int64_t)kPartialBlocks * C; }
+constexpr int kFusedRowsMax = 512;       // upper bound of fused_blocks() the workspace is sized for
+extern "C" int64_t avdf_affine_residual_bwd_ws(int B, int T, int C) { (void)B; (void)T; return (int64_t)kFusedRowsMax * C; }
+// rows of [C] dscale partials that accumulate == 2 leaves in ws (0: that mode is not available for this width)
+extern "C" int avdf_affine_residual_bwd_rows(int B, int T, int C) {
+  return (C % 4 == 0 && kFusedThreads % (C / 4) == 0) ? fused_blocks((long)B * T * C / 4) : 0;
+}
 
 extern "C" int avdf_affine_residual_bwd(const float* dout, const float* ma, const float* r, const float* mr,
                                         const float* scale, const float* keep, float* da, float* dr,
@@ -523,9 +530,12 @@ extern "C" int avdf_affine_residual_bwd(const float* dout, const float* ma, cons
   REQ_C4("affine_residual_bwd", C);
   AVDF_REQUIRE(aligned16(dout) && aligned16(r) && aligned16(scale) && (!da || aligned16(da)) && (!dr || aligned16(dr)), "affine_residual_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
+  // accumulate: 0 overwrite, 1 add (float atomics inside the kernel), 2 leave one row [C] per workgroup in ws for the caller
+  // to ADD (avdf_reduce_segments_batched; rows = avdf_affine_residual_bwd_rows)
   if (accumulate && dscale && (kFusedThreads % (C / 4) == 0)) {
+    AVDF_REQUIRE(accumulate != 2 || ws, "affine_residual_bwd: ws required");
     hipLaunchKernelGGL(affine_residual_bwd_fused_kernel, dim3(fused_blocks((long)B * T * C / 4)), dim3(kFusedThreads), 0, st,
-                       dout, ma, r, mr, scale, keep, da, dr, dscale, B, T, C);
+                       dout, ma, r, mr, scale, keep, da, dr, dscale, accumulate == 2 ? ws : nullptr, B, T, C);
     AVDF_CHECK_LAUNCH("affine_residual_bwd_fused");
     return AVDF_OK;
   }

@@ -148,6 +148,9 @@ def _ws(n, like):
 # engine.TrainStep runs, then folded in ceil(n / 10) launches instead of one dependent tiny launch per chain.
 _DEFERRED = None
 DEFER_REDUCTIONS = _os.environ.get("AVDF_DEFER_REDUCTIONS", "1") != "0"
+# ... and the row kernels (LayerNorm / AffineDropPath backward) hand their workgroups' partial rows to the same fold instead of
+# adding them by float atomics inside the kernel
+DEFER_ROW_PARTIALS = _os.environ.get("AVDF_DEFER_ROWS", "1") != "0"
 
 
 def begin_deferred_reductions():
@@ -171,6 +174,18 @@ def flush_deferred_reductions():
                                            ci([len(j[3]) for j in jobs]), _ptr_table(dst), ci(lens), ci([len(s_) for s_ in srcs]),
                                            ci([(s_ + [0, 0, 0])[k] for s_ in srcs for k in range(3)]), _stream()),
           "reduce_segments_batched")
+
+
+def _affine_residual_bwd(dout, ma, r, mr, sc, keep, da, dr, ds, B, T, C, acc, like):
+    """avdf_affine_residual_bwd; on the engine path the workgroups' dscale rows join the deferred fold of the backward phase
+    instead of float atomics inside the kernel."""
+    ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, C), like) if ds is not None else None
+    rows = int(lib.avdf_affine_residual_bwd_rows(B, T, C)) if (acc and ds is not None and _DEFERRED is not None
+                                                               and DEFER_ROW_PARTIALS) else 0
+    check(lib.avdf_affine_residual_bwd(_p(dout), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(da), _p(dr), _p(ds), _p(ws), B, T,
+                                       C, 2 if rows else acc, _stream()), "affine_residual_bwd")
+    if rows:
+        _DEFERRED.append((ws, rows, C, [ds], [C], [[0]]))
 
 
 def _main_grad(t):
@@ -392,9 +407,7 @@ class Conv1dResidualFn(torch.autograd.Function):
         ds = None
         if ctx.needs_input_grad[5]:
             ds = ctx.smain.view(-1) if acc else torch.empty_like(sc)
-        ws = _ws(lib.avdf_affine_residual_bwd_ws(B, Tout, Cout), h) if ds is not None else None
-        check(lib.avdf_affine_residual_bwd(_p(dout), None, _p(h), None, _p(sc), _p(keep), None, _p(dh), _p(ds), _p(ws), B, Tout,
-                                           Cout, acc, _stream()), "affine_residual_bwd")
+        _affine_residual_bwd(dout, None, h, None, sc, keep, None, dh, ds, B, Tout, Cout, acc, h)
         proxy = _CtxProxy((x, w, mask, None), ctx.cfg, ctx.main, ctx.needs_input_grad[0:3] + (False,) * 3)
         proxy.gmode = getattr(ctx, "gmode", 0)
         dx, dw, db = Conv1dFn.backward(proxy, dh)[0:3]
@@ -456,9 +469,7 @@ class MlpResidualFn(torch.autograd.Function):
         ds = None
         if ctx.needs_input_grad[7]:
             ds = ctx.smain.view(-1) if acc else torch.empty_like(sc)
-        ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, Cout), h2) if ds is not None else None
-        check(lib.avdf_affine_residual_bwd(_p(dout), None, _p(h2), None, _p(sc), _p(keep), None, _p(dh2), _p(ds), _p(ws), B, T,
-                                           Cout, acc, st), "affine_residual_bwd")
+        _affine_residual_bwd(dout, None, h2, None, sc, keep, None, dh2, ds, B, T, Cout, acc, h2)
         g1 = torch.empty_like(pre1)                 # d loss / d pre1 = (dh2 * mask) w2 * gelu'(pre1)
         _timed("conv_bwdpair_k1s1", 4.0 * B * T * Cout * H, lambda: check(
             lib.avdf_conv1d_bwd_pair_dact(1, _ptr_table([dh2]), _ptr_table([w2]), _ptr_table([h1]),
@@ -726,13 +737,18 @@ class LayerNormFn(torch.autograd.Function):
         if g is not None:
             dg = mg.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
             db = mb.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
-        ws = _ws(lib.avdf_layernorm_bwd_ws(M, C), x)
+        nws = int(lib.avdf_layernorm_bwd_ws(M, C))
+        ws = _ws(nws, x)
+        defer = bool(acc) and dg is not None and _DEFERRED is not None and DEFER_ROW_PARTIALS
+        mode = 2 if defer else acc
         if ctx.rs is not None:
             check(lib.avdf_layernorm_bwd_rs(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
-                                            M, C, relu, acc, _p(ctx.rs), _stream()), "layernorm_bwd_rs")
+                                            M, C, relu, mode, _p(ctx.rs), _stream()), "layernorm_bwd_rs")
         else:
             check(lib.avdf_layernorm_bwd(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
-                                         M, C, relu, acc, _stream()), "layernorm_bwd")
+                                         M, C, relu, mode, _stream()), "layernorm_bwd")
+        if defer:
+            _DEFERRED.append((ws, nws // (2 * C), 2 * C, [dg, db], [C, C], [[0], [C]]))
         if acc:
             dg = db = None
         elif dg is not None:
@@ -1072,9 +1088,7 @@ class AffineResidualFn(torch.autograd.Function):
         ds = None
         if ctx.needs_input_grad[4]:
             ds = ctx.main.view(-1) if acc else torch.empty_like(sc)
-        ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, C), r) if ds is not None else None
-        check(lib.avdf_affine_residual_bwd(_p(dout), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(da), _p(dr), _p(ds),
-                                           _p(ws), B, T, C, acc, _stream()), "affine_residual_bwd")
+        _affine_residual_bwd(dout, ma, r, mr, sc, keep, da, dr, ds, B, T, C, acc, r)
         return da, None, dr, None, None if (ds is None or acc) else ds.view(ctx.sshape), None
 
 
@@ -1115,10 +1129,16 @@ class ResidualLnFn(torch.autograd.Function):
             ds, dg, db = ms.view(-1), mg.view(-1), mb.view(-1)
         else:
             ds, dg, db = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
-        ws = _ws(lib.avdf_residual_ln_bwd_ws(B, T, C), out)
+        nws = int(lib.avdf_residual_ln_bwd_ws(B, T, C))
+        ws = _ws(nws, out)
+        defer = bool(acc) and _DEFERRED is not None and DEFER_ROW_PARTIALS
         check(lib.avdf_residual_ln_bwd(_p(dout), _p(dh), _p(out), _p(stats[0]), _p(stats[1]), _p(g), _p(ma), _p(r), _p(mr),
-                                       _p(sc), _p(keep), _p(da), _p(dr), _p(ds), _p(dg), _p(db), _p(ws), B, T, C, acc,
-                                       _stream()), "residual_ln_bwd")
+                                       _p(sc), _p(keep), _p(da), _p(dr), _p(ds), _p(dg), _p(db), _p(ws), B, T, C,
+                                       2 if defer else acc, _stream()), "residual_ln_bwd")
+        if defer:
+            # engine path: the workgroups' partial rows are folded with the other parameter partials of this backward phase
+            # (no float atomics inside the kernel: 128 workgroups x 768 adds onto the same 768 floats)
+            _DEFERRED.append((ws, nws // (3 * C), 3 * C, [ds, dg, db], [C, C, C], [[0], [C], [2 * C]]))
         if acc:
             return da, None, dr, None, None, None, None, None, None
         s0, s1, s2 = ctx.shapes

@@ -223,6 +223,10 @@ int avdf_affine_residual_fwd(const float* a, const float* ma, const float* r, co
                              const float* scale, const float* keep, float* out,
                              int B, int T, int C, void* stream);
 int64_t avdf_affine_residual_bwd_ws(int B, int T, int C);
+/* accumulate == 2 (avdf_affine_residual_bwd, avdf_residual_ln_bwd, avdf_layernorm_bwd): the kernel leaves one row of
+ * parameter partials per workgroup in ws instead of adding them by float atomics; the caller ADDS the rows
+ * (avdf_reduce_segments_batched).  Rows: this function (0 = mode not available for this width) / ws floats / 3C / 2C.  */
+int avdf_affine_residual_bwd_rows(int B, int T, int C);
 int avdf_affine_residual_bwd(const float* dout, const float* ma, const float* r, const float* mr,
                              const float* scale, const float* keep, float* da, float* dr,
                              float* dscale, float* ws, int B, int T, int C, int accumulate, void* stream);
