@@ -12,10 +12,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libavdf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["gemm_conv.hip", "pw_gemm.hip", "norm.hip", "attn.hip", "pointwise.hip", "smallconv.hip", "loss.hip",
-           "decode_nms.hip", "interp.hip", "optim.hip", "audio.hip", "emotion.hip", "video.hip", "chain.hip", "glue.hip", "fpn.hip", "api.cpp"]
+SOURCES = ["gemm_conv.hip", "norm.hip", "attn.hip", "pointwise.hip", "smallconv.hip", "loss.hip",
+           "decode_nms.hip", "interp.hip", "optim.hip", "audio.hip", "emotion.hip", "video.hip", "chain.hip", "glue.hip", "fpn.hip", "block_fused.hip", "api.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"]
+
+
+# AVDF_PW_EXPERIMENTAL=1: also build the wave-specialised pointwise forward core of tools/experimental/pw_gemm/ (round-3
+# experiment, +0.25 % in situ: not part of the product library or of include/avdf.h) and its plan codes >= 8
+PW_EXP = os.environ.get("AVDF_PW_EXPERIMENTAL") == "1"
+PW_DIR = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools", "experimental", "pw_gemm")
 
 
 def _stale(obj, deps):
@@ -23,16 +29,22 @@ def _stale(obj, deps):
 
 
 def build(force=False, verbose=False):
-    obj_dir = os.path.join(HERE, "build")
+    obj_dir = os.path.join(HERE, "build_pwexp" if PW_EXP else "build")
     os.makedirs(obj_dir, exist_ok=True)
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "pw_gemm.h"), os.path.join(HERE, "gemm_tuned.inc"),
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_tuned.inc"),
             os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "avdf.h")]
+    sources = [os.path.join(HERE, s) for s in SOURCES]
+    flags = list(FLAGS)
+    if PW_EXP:
+        sources.append(os.path.join(PW_DIR, "pw_gemm.hip"))
+        hdrs.append(os.path.join(PW_DIR, "pw_gemm.h"))
+        flags += ["-DAVDF_PW_EXPERIMENTAL", "-I", PW_DIR, "-I", HERE]
     jobs = []
-    for s in SOURCES:
-        src = os.path.join(HERE, s)
+    for src in sources:
+        s = os.path.basename(src)
         obj = os.path.join(obj_dir, s.rsplit(".", 1)[0] + ".o")
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -46,7 +58,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(obj_dir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
+    objs = [os.path.join(obj_dir, os.path.basename(s).rsplit(".", 1)[0] + ".o") for s in sources]
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs)
     return OUT

@@ -26,7 +26,9 @@
 // Replaces: MaskedConv1D / nn.Conv1d(k=1) / nn.Linear of libs/modeling/blocks.py:41-63,
 // 957-966, 1291-1297, 1498-1505 and their autograd-generated backward.
 #include "common.h"
-#include "pw_gemm.h"
+#ifdef AVDF_PW_EXPERIMENTAL
+#include "pw_gemm.h"          // tools/experimental/pw_gemm (not part of the product build)
+#endif
 #include <stdlib.h>
 
 // phase-timestamp hook for tools/probe (empty in the product build)
@@ -1262,7 +1264,9 @@ inline TilePlan pick_tile(int B, int T, int N, bool dgrad = false, int K = 0, in
     const int mk_[7] = {1, 2, 4, 4, 2, 4, 4};
     if (g_override[kind][0] >= 0) {
       TilePlan o{g_override[kind][0], g_override[kind][1] & 7, (g_override[kind][1] >> 3) & 1};
-      if (o.tile >= 8) return o;                         // pipelined pointwise core (pw_gemm.hip): (8 + cfg, workgroups per CU)
+#ifdef AVDF_PW_EXPERIMENTAL
+      if (o.tile >= 8 && kind == 0) return o;            // experimental pointwise forward core: (8 + cfg, workgroups per CU)
+#endif
       if (o.tile > 6) o.tile = 6;
       if (o.kg > mk_[o.tile]) o.kg = mk_[o.tile];
       if (o.kg != 1 && o.kg != 2 && o.kg != 4) o.kg = 1;
@@ -1396,6 +1400,7 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
   if (xbs < 0) xbs = (long)Tin * ldx;
   if (ybs < 0) ybs = (long)Tout * ldy;
   TilePlan plan = pick_tile(B * nprob, Tout, Cout, false, K, stride, Cin);
+#ifdef AVDF_PW_EXPERIMENTAL
   if (plan.tile >= 8) {
     // tile codes >= 8 select the pipelined pointwise core: plain row-major GEMM over the token rows, exact fp32 only
     const bool ok = K == 1 && stride == 1 && pad == 0 && B == 1 && wbs == 0 && ldx == Cin && ldw == Cin && ldy == Cout &&
@@ -1417,6 +1422,9 @@ static int conv1d_fwd_launch(const FwdPtrs& ptrs, int nprob, int B, int Tin, int
     }
     plan = TilePlan{2, 1, 0};
   }
+#else
+  if (plan.tile > 6) plan = TilePlan{2, 1, 0};         // table rows of the experimental core (codes >= 8) in a product build
+#endif
 #define LAUNCH_FWD(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                               \
   do {                                                                                                  \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                           \

@@ -261,8 +261,14 @@ class TrainStep:
     def _stage_a(self):
         ops.interp_concat_batched(self.stream_bufs, self.x)
         # the mode a layer's forward is issued under also selects the arithmetic of its backward kernels (bit 1)
-        with ops.gemm_mode(ops.current_gemm_mode() | (1 if self.fwd_bf16x3 else 0) | (2 if self.bwd_bf16x3 else 0)):
-            outs = self._forward()
+        # forward-time fusion decisions (ops.mlp_residual_fusable: the MLP node's backward is the K = 1 pair launch on the
+        # main stream) must see the setting their backward will run under
+        ops.WGRAD_SIDE_STREAM = self.wgrad_side
+        try:
+            with ops.gemm_mode(ops.current_gemm_mode() | (1 if self.fwd_bf16x3 else 0) | (2 if self.bwd_bf16x3 else 0)):
+                outs = self._forward()
+        finally:
+            ops.WGRAD_SIDE_STREAM = False
         st = torch.cuda.current_stream().cuda_stream
         radius, center = self.loss_cfg[0], self.loss_cfg[1]
         check(lib.avdf_loc_assign(self.points.data_ptr(), outs[2].data_ptr(), self.gt.data_ptr(), self.ngt.data_ptr(),
@@ -297,10 +303,14 @@ class TrainStep:
         ops.begin_deferred_reductions()          # the chains' parameter partials of this phase are folded in one go
         try:
             self._run_phase(self._phases[i], retain=self.use_graph)
+        except BaseException:
+            ops.abort_deferred_reductions()      # the phase's own error surfaces, not a fold over half-written partials
+            raise
+        else:
+            ops.flush_deferred_reductions()
         finally:
             ops.WGRAD_SIDE_STREAM = False
             ops.wgrad_join()
-            ops.flush_deferred_reductions()
 
     def _stage_c(self):
         st = torch.cuda.current_stream().cuda_stream
@@ -474,6 +484,102 @@ class TrainStep:
             k, off = named[n].numel(), self._offsets[n]
             out[n] = self.ema[off:off + k].view(named[n].shape).clone()
         return out
+
+
+    # ---- checkpoint-compatible state (libs/utils/train_utils.py:43-56, train.py:115-133) -----------------
+    def _optimizer_order(self):
+        """Parameter order of the reference's optimiser: make_optimizer builds two groups, sorted(decay) then
+        sorted(no_decay) (train_utils.py:122-127); torch.optim numbers parameters in that order."""
+        decay, no_decay = split_decay(self.model)
+        return sorted(decay), sorted(no_decay)
+
+    def state_dict(self):
+        """The reference's checkpoint dict (train_utils.py:43-56 saves {'epoch', 'state_dict', 'state_dict_ema',
+        'scheduler', 'optimizer'}): `state_dict` / `state_dict_ema` under the model's keys, `optimizer` in
+        torch.optim.AdamW.state_dict() layout -- integer parameter ids in make_optimizer's order, per-parameter
+        {'step', 'exp_avg', 'exp_avg_sq'} for every parameter that has received a gradient (dead parameters have no
+        entry, as in torch.optim), two param_groups.  Extra keys carry what the reference keeps in Python attributes:
+        `loss_normalizer` (av_fd_no_recon.py:645-648), `step_count`, and the RNG states of the drop-path draws."""
+        torch.cuda.synchronize(self.dev)
+        named = dict(self.model.named_parameters())
+        decay, no_decay = self._optimizer_order()
+        ids = {n: i for i, n in enumerate(decay + no_decay)}
+        step = torch.tensor(float(self.step_count))
+        state = {}
+        if self.step_count > 0:
+            for n in self.live_names:
+                k, off, shp = named[n].numel(), self._offsets[n], named[n].shape
+                state[ids[n]] = {'step': step.clone(), 'exp_avg': self.exp_avg[off:off + k].view(shp).clone(),
+                                 'exp_avg_sq': self.exp_avg_sq[off:off + k].view(shp).clone()}
+        common = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, amsgrad=False, maximize=False, foreach=None,
+                      capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True)
+        groups = [dict(common, weight_decay=self.wd, params=[ids[n] for n in decay]),
+                  dict(common, weight_decay=0.0, params=[ids[n] for n in no_decay])]
+        return {'state_dict': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                'state_dict_ema': self.ema_state_dict(),
+                'optimizer': {'state': state, 'param_groups': groups},
+                'step_count': self.step_count,
+                'loss_normalizer': self.model._loss_norm_state.detach().clone(),
+                'rng_state': {'cpu': torch.get_rng_state(), 'cuda': torch.cuda.get_rng_state(self.dev)}}
+
+    def load_state_dict(self, ckpt, strict=True):
+        """Inverse of state_dict(); also accepts a checkpoint written by the reference's train.py (optimizer state of a
+        torch.optim.AdamW built by make_optimizer; DataParallel's `module.` prefix on the model keys is dropped).  Weights,
+        EMA and Adam moments go straight into the flat device buffers the captured step reads, so a captured engine
+        resumes without re-capture."""
+        torch.cuda.synchronize(self.dev)
+        named = dict(self.model.named_parameters())
+
+        def unprefixed(sd):
+            return {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+
+        sd = unprefixed(ckpt['state_dict'])
+        missing = [n for n in named if n not in sd]
+        if strict and missing:
+            raise KeyError(f"state_dict lacks {len(missing)} parameters, e.g. {missing[:3]}")
+        with torch.no_grad():
+            for n, p in named.items():              # live parameters are views of flat_p: copy_ writes through
+                if n in sd:
+                    p.copy_(sd[n].to(self.dev))
+            bufs = dict(self.model.named_buffers())
+            for k, v in sd.items():
+                if k in bufs and k not in named:
+                    bufs[k].copy_(v.to(self.dev))
+            ema = unprefixed(ckpt['state_dict_ema']) if ckpt.get('state_dict_ema') is not None else sd
+            for n in self.live_names:
+                k, off = named[n].numel(), self._offsets[n]
+                self.ema[off:off + k].copy_(ema[n].to(self.dev).reshape(-1))
+            decay, no_decay = self._optimizer_order()
+            order = decay + no_decay
+            opt = ckpt.get('optimizer')
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            steps = set()
+            if opt is not None:
+                groups = opt['param_groups']
+                assert [len(g['params']) for g in groups] == [len(decay), len(no_decay)], \
+                    "optimizer param_groups do not match make_optimizer's decay / no-decay partition of this model"
+                flat_ids = [i for g in groups for i in g['params']]
+                for pos, n in enumerate(order):
+                    st = opt['state'].get(flat_ids[pos])
+                    if st is None or n not in self._offsets:
+                        continue
+                    k, off = named[n].numel(), self._offsets[n]
+                    self.exp_avg[off:off + k].copy_(st['exp_avg'].to(self.dev).reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st['exp_avg_sq'].to(self.dev).reshape(-1))
+                    steps.add(int(float(st['step'])))
+                assert len(steps) <= 1, f"per-parameter step counts differ: {sorted(steps)}"
+                self.lr = float(groups[0]['lr'])
+            self.step_count = int(ckpt.get('step_count', steps.pop() if steps else 0))
+            if ckpt.get('loss_normalizer') is not None:
+                self.model._loss_norm_state.copy_(torch.as_tensor(ckpt['loss_normalizer'], dtype=torch.float32).reshape(
+                    self.model._loss_norm_state.shape).to(self.dev))
+            self.flat_g.zero_()
+        rng = ckpt.get('rng_state')
+        if rng is not None:
+            torch.set_rng_state(rng['cpu'])
+            torch.cuda.set_rng_state(rng['cuda'], self.dev)
+        torch.cuda.synchronize(self.dev)
 
 
 class InferStep:

@@ -159,6 +159,22 @@ def begin_deferred_reductions():
         _DEFERRED = []
 
 
+def abort_deferred_reductions():
+    """The backward phase raised: drop the queued jobs (their destinations hold a partial gradient either way) so that
+    the error that surfaces is the phase's own, not a fold over half-written workspaces."""
+    global _DEFERRED
+    _DEFERRED = None
+
+
+def _deferrable(stride, lens, srcs=()):
+    """Constraints of avdf_reduce_segments_batched (chain.hip), checked where a job is QUEUED so that an unsupported width
+    takes the immediate reduction of its call site instead of failing after the phase's kernels have run: row stride
+    <= 65535 floats, segment lengths / source offsets multiples of 4, <= 16 segments, <= 65535 columns per job."""
+    return (_DEFERRED is not None and 0 < stride <= 65535 and stride % 4 == 0 and 0 < len(lens) <= 16
+            and all(n > 0 and n % 4 == 0 for n in lens) and sum(lens) <= 65535
+            and all(o % 4 == 0 for s_ in srcs for o in s_))
+
+
 def flush_deferred_reductions():
     """Launch the queued jobs on the current stream (the stream the backward pass ran on) and stop queueing."""
     global _DEFERRED
@@ -180,8 +196,8 @@ def _affine_residual_bwd(dout, ma, r, mr, sc, keep, da, dr, ds, B, T, C, acc, li
     """avdf_affine_residual_bwd; on the engine path the workgroups' dscale rows join the deferred fold of the backward phase
     instead of float atomics inside the kernel."""
     ws = _ws(lib.avdf_affine_residual_bwd_ws(B, T, C), like) if ds is not None else None
-    rows = int(lib.avdf_affine_residual_bwd_rows(B, T, C)) if (acc and ds is not None and _DEFERRED is not None
-                                                               and DEFER_ROW_PARTIALS) else 0
+    rows = int(lib.avdf_affine_residual_bwd_rows(B, T, C)) if (acc and ds is not None and DEFER_ROW_PARTIALS
+                                                               and _deferrable(C, [C])) else 0
     check(lib.avdf_affine_residual_bwd(_p(dout), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(da), _p(dr), _p(ds), _p(ws), B, T,
                                        C, 2 if rows else acc, _stream()), "affine_residual_bwd")
     if rows:
@@ -739,7 +755,7 @@ class LayerNormFn(torch.autograd.Function):
             db = mb.view(C) if acc else torch.empty(C, dtype=x.dtype, device=x.device)
         nws = int(lib.avdf_layernorm_bwd_ws(M, C))
         ws = _ws(nws, x)
-        defer = bool(acc) and dg is not None and _DEFERRED is not None and DEFER_ROW_PARTIALS
+        defer = bool(acc) and dg is not None and DEFER_ROW_PARTIALS and _deferrable(2 * C, [C, C])
         mode = 2 if defer else acc
         if ctx.rs is not None:
             check(lib.avdf_layernorm_bwd_rs(_p(dy), _p(x), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(ws),
@@ -885,7 +901,7 @@ class QkvChainFn(torch.autograd.Function):
         lens = (ctypes.c_int * nseg)(*seg_len)
         nsrc = (ctypes.c_int * nseg)(*[len(s_) for s_ in seg_src])
         offs = (ctypes.c_int * (nseg * 3))(*[(s_ + [0, 0, 0])[j] for s_ in seg_src for j in range(3)])
-        if acc and _DEFERRED is not None:
+        if acc and _deferrable(21 * C, seg_len, seg_src):
             # engine path: folded together with the other chains of this backward phase (flush_deferred_reductions)
             _DEFERRED.append((wsb, int(lib.avdf_chain_bwd_rows(B, Tin)), 21 * C, seg_dst, seg_len, seg_src))
         else:
@@ -1131,7 +1147,7 @@ class ResidualLnFn(torch.autograd.Function):
             ds, dg, db = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
         nws = int(lib.avdf_residual_ln_bwd_ws(B, T, C))
         ws = _ws(nws, out)
-        defer = bool(acc) and _DEFERRED is not None and DEFER_ROW_PARTIALS
+        defer = bool(acc) and DEFER_ROW_PARTIALS and _deferrable(3 * C, [C, C, C])
         check(lib.avdf_residual_ln_bwd(_p(dout), _p(dh), _p(out), _p(stats[0]), _p(stats[1]), _p(g), _p(ma), _p(r), _p(mr),
                                        _p(sc), _p(keep), _p(da), _p(dr), _p(ds), _p(dg), _p(db), _p(ws), B, T, C,
                                        2 if defer else acc, _stream()), "residual_ln_bwd")

@@ -78,7 +78,7 @@ def pmc_traffic(tag):
         d = json.load(open(path))
         ent = d["by_tag"][_norm_tag(tag)]
         return {"bytes_per_launch": ent["bytes_per_launch"], "fetch_bytes": ent["fetch_bytes"], "write_bytes": ent["write_bytes"],
-                "static": True, "source": os.path.relpath(path, ROOT), "measured_at_commit": d.get("commit", "round-1 build")}
+                "static": True, "source": os.path.relpath(path, ROOT), "measured_at_commit": d.get("commit")}
     except Exception:
         return None
 
@@ -90,7 +90,7 @@ def pmc_mfma_util(tag):
     try:
         d = json.load(open(path))
         return {"kernel": d["by_tag"][_norm_tag(tag)]["mfma_util"], "all_conv_kernels": d["all_conv_kernels"], "static": True,
-                "source": os.path.relpath(path, ROOT), "measured_at_commit": d.get("commit", "round-1 build")}
+                "source": os.path.relpath(path, ROOT), "measured_at_commit": d.get("commit")}
     except Exception:
         return None
 
@@ -186,6 +186,56 @@ def cpu_baseline_e2e(frames_per_sample=24):
                       f"768 frames ({t_enc:.1f}s per clip) + the localisation oracle ({1.0 / loc['value']:.2f}s per clip), {threads} threads"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks ourselves (the single-command
+    multi-device start of the reference: train.py:60-61,101 wraps the model in nn.DataParallel over cfg['devices']).
+    One child `torch.distributed.run` with one worker per GPU over RCCL; this parent makes NO GPU call (counting devices
+    does not initialise the runtime) and exits with the child's code.  Fewer than N visible devices is an error, not a
+    silent single-GPU run -- unless AVDF_DIST_BACKEND=gloo asks for the rehearsal mode in which ranks share devices."""
+    import socket
+    import subprocess
+    backend = os.environ.get("AVDF_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {ndev}; refusing to run a smaller job under that label "
+              f"(AVDF_DIST_BACKEND=gloo rehearses the N-rank path on fewer devices)", file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse(args, world, rank):
+    """AVDF_BENCH_REHEARSE=1: the launch + rendezvous + reporting protocol of an N-rank run without the device work
+    (tests/test_bench_launch_cpu.py on a GPU-less host): every rank joins the group, proves the collective with a SUM
+    all-reduce and the MAX-over-ranks timing reduction, rank 0 prints the line's launch-dependent fields."""
+    backend = os.environ.get("AVDF_DIST_BACKEND", "gloo")
+    assert backend == "gloo", "the rehearsal runs on the host"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.distributed.init_process_group("gloo")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("avdf_dp", os.path.join(ROOT, "audio_visual_deepfake_detection_amd", "dp.py"))
+    dp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dp)                      # by path: the package import loads libavdf_hip.so, not needed here
+    lo, hi = dp.shard_range(world * args.batch, rank, world)
+    t = torch.tensor([float(hi - lo), float(rank)], dtype=torch.float64)
+    torch.distributed.all_reduce(t)
+    tmax = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "global_batch": int(t[0].item()), "rank_sum": int(t[1].item()),
+                          "max_over_ranks_s": float(tmax.item()), "config": {"parallelism": f"dp{world}"}}), flush=True)
+    torch.distributed.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,10 +263,17 @@ def main():
                     help="train (headline), infer (K1 -> fwd -> decode+NMS), e2e (raw PCM + frames -> 3 encoders -> infer)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+              f"(or run `python bench.py --gpus {args.gpus}` with no WORLD_SIZE set: it starts the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("AVDF_BENCH_REHEARSE") == "1":
+        sys.exit(rehearse(args, world, rank))
     # AVDF_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # collectives staged through the host); the measured configuration is always one rank per GPU over RCCL ("nccl")
     backend = os.environ.get("AVDF_DIST_BACKEND", "nccl")

@@ -100,16 +100,8 @@ int avdf_conv1d_bwd_pair_dact(int n, const float* const* dy, const float* const*
 
 /* Tuner hook: force the plan of every following launch of a kind (0 fwd, 1 dgrad: (tile 0..4, K-groups + 8*double
  * buffer); 2 wgrad: (token splits, K-groups); 4 backward pair: (dgrad tile, K-groups | wgrad splits << 3)); a = -1
- * restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only.  Forward plans a >= 8 select the
- * wave-specialised pointwise core of csrc/pw_gemm.hip for K = 1, stride 1 launches it supports (configuration a - 8,
- * b = workgroups per CU, 0 = what its LDS allows); launches it does not support keep a table-kernel plan.          */
+ * restores table + heuristic, a = -2 heuristic only.  tools/autotune.py only.                                           */
 int avdf_gemm_override(int kind, int a, int b);
-/* Diagnostics of the pointwise core (tools/pwgemm_bench.py, tests): launches it has served so far; a device buffer of
- * 8 x uint64 per workgroup x 3 wave roles for its in-kernel s_memtime phase stamps (NULL = off, the default); ablation
- * switches (2 no epilogue items, 4 no operand DMAs, 8 no priority raise; 0 = off, the default).                     */
-int avdf_pw_launch_count(void);
-int avdf_pw_stamps(void* buf);
-int avdf_pw_flags(int flags);
 /* Tuner hook (tools/plan_search.py): replace the process's AVDF_TUNED_EXTRA plan rows ("kind,K,stride,M,N,Kred,a,b;...";
  * kinds 3 / 5 / 6 = forward / backward pair / dgrad in split-bf16 mode); NULL or "" clears them.                    */
 int avdf_tuned_extra(const char* rows);
@@ -439,6 +431,33 @@ int avdf_chain_bwd_map(const float* const* dy, const float* const* u, const floa
                        const float* const* beta_a, const float* const* w, const float* const* gamma_b,
                        const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
                        const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream);
+/* ---- row-block fused kernels of one conv-attention block (csrc/block_fused.hip; C = 256) ---------------------------
+ * A workgroup owns 32 complete token rows, so LayerNorm, 1x1 projection, bias, mask and residual chain in one launch;
+ * depthwise k3 and banded attention read a halo of their INPUT.  One attention half-block
+ * (libs/modeling/blocks.py:1152-1224,1307-1313 / 783-876) = two launches.
+ *
+ * avdf_qkv_fused_fwd: avdf_chain_fwd_map (LN_a -> depthwise k3 stride s * mask -> LN_b of q, k, v) followed by the three
+ * 1x1 projections proj[i] = y[i] pw[i]^T + pb[i] (pw[i] = Conv1d weight [C, C, 1] as it lies; pb may be NULL or hold
+ * NULLs).  u / y / stats_a / stats_b are the tensors avdf_chain_bwd* and the projections' backward read: pass all four
+ * tables (training) or all NULL (inference: nothing but proj is written).  xshift may be NULL.                       */
+int avdf_qkv_fused_fwd(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
+                       const float* const* w, const float* const* gamma_b, const float* const* beta_b,
+                       const float* const* pw, const float* const* pb, const float* mask, float* const* u,
+                       float* const* y, float* const* stats_a, float* const* stats_b, float* const* proj,
+                       const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps, void* stream);
+/* 1 if avdf_attn_out_fused_fwd has a kernel for (C, heads, window): C = 256, heads in {1,2,4,8}, window in {3,5,7,9}. */
+int avdf_attn_out_fused_supported(int C, int H, int window);
+/* avdf_local_attn_fwd_ex -> avdf_conv1d_fwd (output projection, * mask) -> avdf_residual_ln_fwd in one launch:
+ *   att = softmax_band(q k^T / sqrt(hs) [+ rel]) [* tw] v;   r = (att pw^T + pb) * mask[row];
+ *   out = skip * mask[row] + scale[c] * keep[b] * r;         h = LN(out) * gamma + beta.
+ * mask [B, T] is the key mask and the row mask (the fused block path has one mask per level); keep may be NULL.
+ * att [B,T,C], probs [B,T,H,window], r [B,T,C], stats [2, B*T] (mean | rstd) are what avdf_local_attn_bwd_ex, the
+ * projection's backward and avdf_residual_ln_bwd read: all four (training) or all NULL (inference).                  */
+int avdf_attn_out_fused_fwd(const float* q, const float* k, const float* v, const float* mask, const float* rel,
+                            const float* tw, const float* pw, const float* pb, const float* skip, const float* scale,
+                            const float* keep, const float* gamma, const float* beta, float* att, float* probs, float* r,
+                            float* stats, float* out, float* h, int B, int T, int C, int H, int window, float eps,
+                            void* stream);
 /* dst[s][i] (+)= sum over rows r < nrow and sources j < nsrc[s] of ws[r*row_stride + src_off[s*3+j] + i],
  * i < len[s]; up to 16 segments per launch (host arrays).                                                   */
 int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,

@@ -328,3 +328,71 @@ def _zero_by_construction(name):
     # a conv bias in front of an InstanceNorm over time and the key bias under the softmax have zero gradient
     # mathematically; what the kernels produce there is cancellation noise in either arithmetic
     return name.endswith("conv_block.conv.bias") or name.endswith(".key.bias")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_state_dict_resume_is_bit_exact_and_loads_into_torch_adamw(use_graph):
+    """TrainStep.state_dict() / load_state_dict() (reference: save_checkpoint, libs/utils/train_utils.py:43-56; resume,
+    train.py:115-133): 3 steps -> save -> FRESH engine (other initial weights) -> load -> 3 steps equals 6 straight
+    steps bit for bit in deterministic mode (drop-path active: its RNG stream is part of the state), and the
+    `optimizer` entry loads into a torch.optim.AdamW built with make_optimizer's partition."""
+    from audio_visual_deepfake_detection_amd import build_model
+    from audio_visual_deepfake_detection_amd.engine import TrainStep, split_decay
+
+    def engine(seed):
+        torch.manual_seed(seed)
+        model, _ = build_model("deepfake_exp10.yaml", **SMALL)
+        eng = TrainStep(model.to("cuda:0"), 4, STREAMS, lr=1e-3, weight_decay=0.05, use_graph=use_graph, deterministic=True)
+        _fill(eng, 11)
+        eng.capture()
+        return eng
+
+    torch.cuda.manual_seed(77)
+    a = engine(1)
+    for _ in range(3):
+        a.step()
+    ckpt = a.state_dict()
+    mid_losses = a.losses()
+    for _ in range(3):
+        a.step()
+    torch.cuda.synchronize()
+    want_p, want_m, want_v, want_e = a.flat_p.clone(), a.exp_avg.clone(), a.exp_avg_sq.clone(), a.ema.clone()
+    want_norm, want_losses = a.model._loss_norm_state.clone(), a.losses()
+
+    # the checkpoint has the reference's keys and torch.optim's layout
+    assert {"state_dict", "state_dict_ema", "optimizer"} <= set(ckpt)
+    decay, no_decay = split_decay(a.model)
+    assert [len(g["params"]) for g in ckpt["optimizer"]["param_groups"]] == [len(decay), len(no_decay)]
+    assert all(float(s["step"]) == 3.0 for s in ckpt["optimizer"]["state"].values())
+    assert len(ckpt["optimizer"]["state"]) == len(a.live_names)
+
+    b = engine(2)                                   # different initial weights, different RNG position
+    assert not torch.equal(b.flat_p, a.flat_p)
+    b.load_state_dict(ckpt)
+    assert b.step_count == 3 and b.losses is not None
+    for _ in range(3):
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(b.flat_p, want_p) and torch.equal(b.exp_avg, want_m) and torch.equal(b.exp_avg_sq, want_v)
+    assert torch.equal(b.ema, want_e) and torch.equal(b.model._loss_norm_state, want_norm)
+    assert b.losses() == want_losses and b.losses() != mid_losses
+
+    # hand-over to torch.optim.AdamW built by the reference's partition rules (train_utils.py:122-134)
+    ref, _ = build_model("deepfake_exp10.yaml", **SMALL)
+    ref = ref.to("cuda:0")
+    ref.load_state_dict(ckpt["state_dict"])
+    named = dict(ref.named_parameters())
+    opt = torch.optim.AdamW([{"params": [named[n] for n in sorted(decay)], "weight_decay": 0.05},
+                             {"params": [named[n] for n in sorted(no_decay)], "weight_decay": 0.0}], lr=1e-3)
+    opt.load_state_dict(ckpt["optimizer"])
+    n0 = a.live_names[0]
+    st = opt.state[named[n0]]
+    off, k = a._offsets[n0], named[n0].numel()
+    assert float(st["step"]) == 3.0 and st["exp_avg"].shape == named[n0].shape
+    # and back: the torch optimiser's own state_dict resumes the engine to the same trajectory
+    c = engine(3)
+    c.load_state_dict(dict(ckpt, optimizer=opt.state_dict(), state_dict={"module." + k_: v for k_, v in ckpt["state_dict"].items()}))
+    for _ in range(3):
+        c.step()
+    torch.cuda.synchronize()
+    assert torch.equal(c.flat_p, want_p) and torch.equal(c.exp_avg_sq, want_v)

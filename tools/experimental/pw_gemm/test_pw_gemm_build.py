@@ -1,4 +1,4 @@
-"""Build-time invariant of csrc/pw_gemm.hip (no GPU): none of its kernels may use scratch.  The MFMA waves read their
+"""Build-time invariant of tools/experimental/pw_gemm/pw_gemm.hip (no GPU; run by path: `pytest tools/experimental/pw_gemm`): none of its kernels may use scratch.  The MFMA waves read their
 operand fragments by inline-asm ds_read_b128 whose results become valid only at a later s_waitcnt; a register spill (or any
 compiler-inserted copy) between the two would save a stale value.  Zero scratch is the part of that contract a test can
 hold."""
@@ -9,7 +9,8 @@ import subprocess
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+PW = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, "audio_visual_deepfake_detection_amd", "csrc")
 
 
@@ -18,7 +19,7 @@ def test_pw_gemm_kernels_use_no_scratch(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = tmp_path / "pw_gemm.s"
     subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-S", "--cuda-device-only",
-                    "-I", CSRC, "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "pw_gemm.hip"), "-o", str(out)],
+                    "-I", CSRC, "-I", PW, "-I", os.path.join(ROOT, "include"), os.path.join(PW, "pw_gemm.hip"), "-o", str(out)],
                    check=True, capture_output=True, timeout=600)
     asm = out.read_text()
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S)

@@ -2,9 +2,11 @@
 the un-instrumented average duration (rNN_*_kernel_stats.csv).   python tools/hbm_table.py profiles/r02_a > profiles/r02_a_hbm_kernels.md"""
 import csv, json, sys
 stem = sys.argv[1]
-tr = json.load(open(stem + "_pmc_traffic.json"))["by_kernel"]
+sep = "" if stem.endswith("/") else "_"            # profiles/r04_a (files r04_a_*.json) or a directory gpurun_out/prof_x/
+doc = json.load(open(stem + sep + "pmc_traffic.json"))
+tr = doc["by_kernel"]
 strip = lambda n: n[5:] if n.startswith("void ") else n
-stats = {strip(r["Name"]): (int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(stem + "_kernel_stats.csv"))}
+stats = {strip(r["Name"]): (int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(stem + sep + "kernel_stats.csv"))}
 rows = []
 for name, e in tr.items():
     n = strip(name)
@@ -15,6 +17,7 @@ for name, e in tr.items():
 rows.sort(reverse=True)
 short = lambda n: n.replace("(anonymous namespace)::", "").split("(")[0][:64]
 print("# HBM-side traffic and achieved bandwidth of the non-GEMM kernels (training step, 8 clips)\n")
+print(f"measured at commit `{doc.get('commit')}`\n")
 print("PMC bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes), averaged over all launches of a kernel (all pyramid\n"
       "levels); duration = un-instrumented average of the kernel trace.  Peak HBM rate 8 TB/s; most of these launches move < 10 MB and sit on the\n"
       "~5 us launch floor, so the fraction says how far a kernel is from being bandwidth-limited at all (L2 / Infinity-Cache hits do not count).\n")

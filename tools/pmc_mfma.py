@@ -14,7 +14,7 @@ denominator comes from the plain kernel trace:
 mfma_util is directly comparable with roofline.frac: the gap between the two is padded / non-algorithmic MFMA work."""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(__file__))
-from pmc_summary import tag_of
+from pmc_summary import tag_of, head_commit
 
 SIMDS, XCDS, GHZ = 256 * 4, 8, 2.4
 
@@ -54,7 +54,7 @@ def main():
     out_t = {k: {"launches": v["launches"], "mfma_util": round(v["busy"] / (SIMDS * v["ns"] * GHZ), 4),
                  "mfma_util_pmc_run": round(v["busy"] / (v["gui"] / XCDS * SIMDS), 4)} for k, v in tags.items()}
     tb, tn = sum(v["busy"] for v in tags.values()), sum(v["ns"] for v in tags.values())
-    out = {"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x un-instrumented avg duration x 2.4 GHz)",
+    out = {"commit": head_commit(), "note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES per launch / (1024 SIMDs x un-instrumented avg duration x 2.4 GHz)",
            "all_conv_kernels": round(tb / (SIMDS * tn * GHZ), 4), "by_tag": out_t, "by_kernel": out_k}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out_t.items()):

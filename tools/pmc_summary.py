@@ -19,6 +19,20 @@ def load(d, counter):
     return agg
 
 
+def head_commit():
+    """Commit the measured snapshot was taken from: $AVDF_COMMIT, else .gpurun_commit (written by tools/gpu.sh before the
+    snapshot travels to the GPU box, which has no .git), else `git rev-parse` where a repository exists."""
+    c = os.environ.get("AVDF_COMMIT")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not c and os.path.exists(os.path.join(root, ".gpurun_commit")):
+        c = open(os.path.join(root, ".gpurun_commit")).read().strip()
+    if not c:
+        import subprocess
+        r = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True)
+        c = r.stdout.strip() if r.returncode == 0 else None
+    return c or None
+
+
 def tag_of(name):
     """bench.py roofline class of a rocprof kernel name: conv_{fwd,dgrad,wgrad}_k{K}s{S} (all tile variants folded;
     the grouped q/k/v launches run the same kernels and are folded in too)."""
@@ -48,7 +62,7 @@ def main():
                    "bytes_per_launch": round((v["f"] + v["w"]) / v["launches"])} for k, v in by_tag.items()}
     # grouped q/k/v launches carry the fwd3 / dgrad3 tags in bench.py: same kernels, 3 problems per launch; they are
     # folded into the plain tags here (rocprof cannot tell them apart)
-    json.dump({"note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes",
+    json.dump({"commit": head_commit(), "note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate rocprofv3 --pmc passes",
                "by_tag": out_tag, "by_kernel": by_kernel}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out_tag.items()):
         print(f"{k:32s} n={v['launches']:5d} fetch={v['fetch_bytes']/1e6:8.2f} MB write={v['write_bytes']/1e6:8.2f} MB")
