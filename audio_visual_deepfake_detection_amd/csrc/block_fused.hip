@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, (S == 1 ? 2 : 1)) void qkv_fused_fwd_kernel(Qk
   wchunk_load(pre, a.pw[br], 0, tid);          // in flight under the whole chain phase
 
   // ---- z = LN_a(x) for input rows to0*S-1 .. (to0+R-1)*S+1 (zero rows outside the clip: the conv's padding) ----------
+#ifndef BF_NO_CHAIN
   {
     const float* __restrict__ x = a.x[br];
     const float4 g = a.ga[br] ? ld4(a.ga[br] + c) : f4(1.f), bt = a.ga[br] ? ld4(a.ba[br] + c) : f4(0.f);
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, (S == 1 ? 2 : 1)) void qkv_fused_fwd_kernel(Qk
       st4(ybuf + i * kAS + c, yv);
     }
   }
+#endif
   __syncthreads();                              // z is consumed: its LDS becomes the weight buffer
   // ---- projection ----------------------------------------------------------------------------------------------------
   floatx16 acc[2];
@@ -201,8 +203,13 @@ __global__ __launch_bounds__(256, (S == 1 ? 2 : 1)) void qkv_fused_fwd_kernel(Qk
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#ifndef BF_NO_GEMM
   rowblock_gemm(ybuf, zw, a.pw[br], pre, acc, tid);
+#endif
   float* __restrict__ o = a.o[br];
+#ifdef BF_NO_EPI
+  if (acc[0][0] == 12345.f)
+#endif
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int col = wid * 64 + t * 32 + (lane & 31);
@@ -403,7 +410,8 @@ extern "C" int avdf_qkv_fused_fwd(const float* const* x, const float* const* gam
 extern "C" int avdf_attn_out_fused_supported(int C, int H, int window) {
   if (C != kC || H <= 0 || 64 % H != 0) return 0;
   const int L = 64 / H;
-  return (L == 8 || L == 16 || L == 32 || L == 64) && (window == 3 || window == 5 || window == 7 || window == 9);
+  // head size <= 64 like avdf_local_attn_bwd_ex, which runs this launch's backward
+  return (L == 8 || L == 16) && (window == 3 || window == 5 || window == 7 || window == 9);
 }
 
 // Banded attention + output projection + AffineDropPath residual + LN2 of one block in one launch (C = 256):
@@ -429,7 +437,7 @@ extern "C" int avdf_attn_out_fused_fwd(const float* q, const float* k, const flo
   const float qk_scale = 1.0f / sqrtf((float)(C / H));
   hipStream_t st = (hipStream_t)stream;
 #define AO_L(W_, L_) hipLaunchKernelGGL((attn_out_fused_fwd_kernel<W_, L_>), dim3(B * tiles), dim3(256), 0, st, a, B, T, qk_scale, eps, tiles)
-#define AO_W(W_) do { if (L == 8) AO_L(W_, 8); else if (L == 16) AO_L(W_, 16); else if (L == 32) AO_L(W_, 32); else AO_L(W_, 64); } while (0)
+#define AO_W(W_) do { if (L == 8) AO_L(W_, 8); else AO_L(W_, 16); } while (0)
   switch (window) {
     case 3: AO_W(3); break;
     case 5: AO_W(5); break;

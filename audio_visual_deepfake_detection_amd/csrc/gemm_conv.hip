@@ -1129,14 +1129,32 @@ __global__ __launch_bounds__(64 * WM * WN * KGD, ((!BF3 && WM == 1 && WN == 4 &&
   constexpr int SM = cmax(dgrad_smem_floats<1, 1, WM, WN, MI, NI, KC, KGD, false, BF3>(),
                           wgrad_smem_floats<1, 1, 2, 2, 1, 1, 128, KG, BF3>());
   __shared__ __attribute__((aligned(16))) float smem[SM];
-  int id = blockIdx.x;
-  if (id < nW) {
+  // XCD-aware work order (round 4).  Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, each
+  // with its own 4 MiB L2): in grid order the wgrad workgroups that share an x token chunk (same token split, different
+  // n tile) sat on different XCDs, so every XCD pulled the whole x (and every dy column slab) through the fabric --
+  // 63.6 MB fetched per launch against ~25 MB algorithmic (profiles/r03_l_pmc_traffic.txt).  Here XCD c gets the c-th
+  // eighth of the wgrad items in (token split, c tile, n tile) order followed by the c-th eighth of the dgrad items in
+  // (row tile, column tile) order: the token range of an XCD's weight-gradient splits is the row range of its
+  // data-gradient tiles, so dy and x rows cross the fabric once and are shared through that XCD's L2.  Placement is a
+  // speed matter only (MI355X_MICROARCH.md: no dispatch-order guarantee): any block -> XCD map gives the same results.
+  const int G = gridDim.x, hw = blockIdx.x;
+  const int xcd = hw & 7;
+  // position in XCD-major order (tilesT < 0: grid order, the A/B switch AVDF_PAIR_XCD=0)
+  const int v = tilesT < 0 ? hw : xcd * (G >> 3) + min(xcd, G & 7) + (hw >> 3);
+  if (tilesT < 0) tilesT = -tilesT;
+  int c = 0;
+  while (c < 7 && v >= (int)(((long)(c + 1) * nW) >> 3) + (int)(((long)(c + 1) * (G - nW)) >> 3)) ++c;
+  const int w0 = (int)(((long)c * nW) >> 3), w1 = (int)(((long)(c + 1) * nW) >> 3), d0 = (int)(((long)c * (G - nW)) >> 3);
+  const int local = v - (w0 + d0);
+  if (local < w1 - w0) {
+    const int id = w0 + local;
     const int bx = id % wgx, by = (id / wgx) % wgy, bz = id / (wgx * wgy);
     conv_wgrad_body<1, 1, 2, 2, 1, 1, 128, KG, true, BF3>(smem, wp, mtiles, B, T, Cin, T, Cout, act, tilesPerClip,
                                                           tilesPerSplit, 1, bx, by, bz, wgz);
   } else {
-    id -= nW;
-    const int bx = id % dgx, by = (id / dgx) % dgy, bz = id / (dgx * dgy);
+    const int id = d0 + local - (w1 - w0);
+    const int nprob = (G - nW) / (dgx * dgy);                              // row tile slowest, then problem, then column tile
+    const int by = id % dgy, bz = (id / dgy) % nprob, bx = id / (dgy * nprob);
     conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KGD, false, BF3>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
   }
 }
@@ -1780,6 +1798,7 @@ extern "C" int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, con
 // dw[i] / dbias[i] with float atomics (the engine's flat-gradient path); dx[i] is overwritten.  g_pair_mode 0 turns
 // the fusion off (two launches, the reference point of tools/gemm_bench.py).
 static int g_pair_mode = [] { const char* e = getenv("AVDF_BWD_PAIR"); return e ? atoi(e) : 1; }();
+static const int g_pair_xcd = [] { const char* e = getenv("AVDF_PAIR_XCD"); return e ? atoi(e) : 1; }();   // 0: grid order (A/B)
 extern "C" int avdf_bwd_pair_mode(int mode) { g_pair_mode = mode; return AVDF_OK; }
 
 extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const float* const* w, const float* const* x,
@@ -1854,8 +1873,9 @@ extern "C" int avdf_conv1d_bwd_pair_dact(int n, const float* const* dy, const fl
 #define LAUNCH_PAIR(KS_, S_, KC_, WM_, WN_, MI_, NI_, KG_)                                                          \
   do {                                                                                                              \
     constexpr int BM_ = WM_ * MI_ * 32, BN_ = WN_ * NI_ * 32;                                                       \
-    const int tilesT = cdiv(T, BM_);                                                                                \
-    const int dgx = B * tilesT, dgy = cdiv(Cin, BN_);                                                               \
+    const int tilesT0 = cdiv(T, BM_);                                                                               \
+    const int tilesT = g_pair_xcd ? tilesT0 : -tilesT0;                                                             \
+    const int dgx = B * tilesT0, dgy = cdiv(Cin, BN_);                                                              \
     const int wgx = p.mtiles * n, wgy = p.ctiles, wgz = p.splits;                                                   \
     const int nW = wgx * wgy * wgz, nD = dgx * dgy * n;                                                             \
     if constexpr ((WM_ * WN_ * KG_) % 4 == 0 && (KC_ / KG_) % 16 == 0) {                                            \

@@ -445,7 +445,7 @@ int avdf_qkv_fused_fwd(const float* const* x, const float* const* gamma_a, const
                        const float* const* pw, const float* const* pb, const float* mask, float* const* u,
                        float* const* y, float* const* stats_a, float* const* stats_b, float* const* proj,
                        const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps, void* stream);
-/* 1 if avdf_attn_out_fused_fwd has a kernel for (C, heads, window): C = 256, heads in {1,2,4,8}, window in {3,5,7,9}. */
+/* 1 if avdf_attn_out_fused_fwd has a kernel for (C, heads, window): C = 256, heads in {4, 8}, window in {3,5,7,9}. */
 int avdf_attn_out_fused_supported(int C, int H, int window);
 /* avdf_local_attn_fwd_ex -> avdf_conv1d_fwd (output projection, * mask) -> avdf_residual_ln_fwd in one launch:
  *   att = softmax_band(q k^T / sqrt(hs) [+ rel]) [* tw] v;   r = (att pw^T + pb) * mask[row];
