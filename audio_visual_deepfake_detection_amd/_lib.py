@@ -109,9 +109,6 @@ SIGNATURES = {
     "avdf_chain_bwd_res": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P]),
     "avdf_chain_bwd_map": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, P]),
     "avdf_chain_bwd_folds": (I, [I, I]),
-    "avdf_qkv_fused_fwd": (I, [P] * 15 + [I] * 5 + [F, P]),
-    "avdf_attn_out_fused_supported": (I, [I, I, I]),
-    "avdf_attn_out_fused_fwd": (I, [P] * 19 + [I] * 5 + [F, P]),
     "avdf_reduce_segments": (I, [P, I, I, I, P, P, P, P, I, P]),
     "avdf_reduce_segments_batched": (I, [I, P, P, P, P, P, P, P, P, P]),
     "avdf_conv3d_k3": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),

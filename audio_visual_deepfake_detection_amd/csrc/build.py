@@ -13,7 +13,7 @@ OUT = os.path.join(os.path.dirname(HERE), "libavdf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 SOURCES = ["gemm_conv.hip", "norm.hip", "attn.hip", "pointwise.hip", "smallconv.hip", "loss.hip",
-           "decode_nms.hip", "interp.hip", "optim.hip", "audio.hip", "emotion.hip", "video.hip", "chain.hip", "glue.hip", "fpn.hip", "block_fused.hip", "api.cpp"]
+           "decode_nms.hip", "interp.hip", "optim.hip", "audio.hip", "emotion.hip", "video.hip", "chain.hip", "glue.hip", "fpn.hip", "api.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"]
 

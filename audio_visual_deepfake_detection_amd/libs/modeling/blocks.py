@@ -221,15 +221,13 @@ class _MHCABase(nn.Module):
         y, out_mask = conv(x, mask)
         return ops.conv1d(norm(y), proj.weight, proj.bias), out_mask
 
-    def attend_prenorm(self, xs, lns, masks, kv_shift=0, tail=None):
+    def attend_prenorm(self, xs, lns, masks, kv_shift=0):
         """Block entry: pre-LayerNorms `lns` (ln1 x3 | lnq, lnk, lnv) + attention on raw inputs `xs`.  When the
         three branches share length and mask (every call site of the shipped backbones) the LN -> depthwise conv
         -> LN chains of q, k, v run as ONE fused launch (ops.qkv_chain); otherwise the per-op path.
         kv_shift != 0: x_k / x_v are given at THEIR pyramid level and stand for their nearest resampling to x_q's length
         (> 0: up by 2^s, < 0: every 2^-s-th row -- backbones.py:487-490); the fused launch reads them through a row map,
-        the per-op path resamples them first.
-        tail (optional): callable (q, k, v, out_mask, x_res) -> result or None, tried on the fused path right after the
-        projections; a non-None result is returned as is (the block's fused attention tail, _BlockBase._fused_tail)."""
+        the per-op path resamples them first."""
         x_q, x_k, x_v = xs
         C = x_q.shape[-1]
         if kv_shift:
@@ -250,28 +248,15 @@ class _MHCABase(nn.Module):
             out_mask = downsample_mask(masks[0], self.n_kv_stride)
             norms = (self.query_norm, self.key_norm, self.value_norm)
             pt = torch.is_grad_enabled() and x_q.requires_grad
-            ln_a = [(ln.weight, ln.bias) for ln in lns]
-            dws = [self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight]
-            ln_b = [(n.weight, n.bias) for n in norms]
-            pws = (self.query.weight, self.key.weight, self.value.weight)
-            pbs = (self.query.bias, self.key.bias, self.value.bias)
-            xshift = (0, kv_shift, kv_shift) if kv_shift else None
-            if ops.qkv_fused_ok(C, pbs):
-                # chains AND projections in one row-block launch (csrc/block_fused.hip)
-                res = ops.qkv_fused(xs, ln_a, dws, ln_b, pws, pbs, out_mask, self.n_kv_stride, lns[0].eps, passthrough=pt,
-                                    xshift=xshift)
-                q, k, v = res[:3]
-                x_res = res[3] if pt else x_q
-            else:
-                ys = ops.qkv_chain(xs, ln_a, dws, ln_b, out_mask, self.n_kv_stride, lns[0].eps, passthrough=pt, xshift=xshift)
-                q, k, v = ops.conv1d_group3(ys[:3], pws, pbs)
-                # ys[3] (training): x_q handed back by the chain op for the caller's residual connection
-                x_res = ys[3] if pt else x_q
-            if tail is not None:
-                done = tail(q, k, v, out_mask, x_res)           # block-level fused attention + projection + residual + LN2
-                if done is not None:
-                    return done
-            return (*self._core(q, k, v, out_mask, out_mask), x_res)
+            ys = ops.qkv_chain(
+                xs, [(ln.weight, ln.bias) for ln in lns],
+                [self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight],
+                [(n.weight, n.bias) for n in norms], out_mask, self.n_kv_stride, lns[0].eps, passthrough=pt,
+                xshift=(0, kv_shift, kv_shift) if kv_shift else None)
+            q, k, v = ops.conv1d_group3(ys[:3], (self.query.weight, self.key.weight, self.value.weight),
+                                        (self.query.bias, self.key.bias, self.value.bias))
+            # ys[3] (training): x_q handed back by the chain op for the caller's residual connection
+            return (*self._core(q, k, v, out_mask, out_mask), ys[3] if pt else x_q)
         if kv_shift:                      # fused launch not applicable after all (masks / LayerNorm variants): resample first
             r = 1 << abs(kv_shift)
             x_k = ops.upsample(x_k, r) if kv_shift > 0 else ops.downsample(x_k, r)
@@ -374,40 +359,21 @@ class _BlockBase(nn.Module):
             self.drop_path_mlp = nn.Identity()
             self.register_buffer("_ones", torch.ones(n_embd), persistent=False)
 
-    def _drop_path_factors(self, B, device):
-        if isinstance(self.drop_path_attn, AffineDropPath):
-            return (self.drop_path_attn.scale, self.drop_path_attn.sample_keep(B, device),
-                    self.drop_path_mlp.scale, self.drop_path_mlp.sample_keep(B, device))
-        return self._ones, None, self._ones, None
-
-    def _fused_tail(self, q, k, v, out_mask, x_res):
-        """Attention core + output projection + first residual + LN2 as ONE launch (ops.attn_out_fused), then the MLP
-        half; None when the block's shape has no fused kernel (global attention, other widths, ...)."""
-        attn = self.attn
-        if not (q.is_cuda and attn.window_size > 1 and attn.proj.bias is not None
-                and ops.attn_out_fused_ok(q.shape[-1], attn.n_head, attn.window_size, self.ln2.affine)
-                and q.shape[1] % (2 * attn.window_overlap) == 0):
-            return None
-        skip = ops.maxpool3s2(x_res) if self.stride > 1 else x_res
-        sa, ka, sm, km = self._drop_path_factors(x_res.shape[0], x_res.device)
-        out, h = ops.attn_out_fused(q, k, v, out_mask, attn.n_head, attn.window_size,
-                                    attn.rel_pe if attn.use_rel_pe else None,
-                                    attn.time_weighting if attn.use_time_weight else None, attn.proj.weight, attn.proj.bias,
-                                    skip, sa, ka, self.ln2.weight, self.ln2.bias, self.ln2.eps)
-        return self._mlp_tail(out, h, out_mask, sm, km), out_mask
-
     def _residual_mlp(self, x, out, out_mask):
         """blocks.py:1311-1313 / 870-872: skip*mask + dp(attn); then + dp(mlp(ln2(.))*mask)."""
+        B = x.shape[0]
         skip = ops.maxpool3s2(x) if self.stride > 1 else x
-        sa, ka, sm, km = self._drop_path_factors(x.shape[0], x.device)
+        if isinstance(self.drop_path_attn, AffineDropPath):
+            sa, ka = self.drop_path_attn.scale, self.drop_path_attn.sample_keep(B, x.device)
+            sm, km = self.drop_path_mlp.scale, self.drop_path_mlp.sample_keep(B, x.device)
+        else:
+            sa = sm = self._ones
+            ka = km = None
         if self.ln2.affine:
             out, h = ops.residual_ln(skip, out_mask, out, None, sa, ka, self.ln2.weight, self.ln2.bias, self.ln2.eps)
         else:
             out = ops.affine_residual(skip, out_mask, out, None, sa, ka)
             h = self.ln2(out)
-        return self._mlp_tail(out, h, out_mask, sm, km)
-
-    def _mlp_tail(self, out, h, out_mask, sm, km):
         if ops.mlp_residual_fusable(h, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, out):
             return ops.mlp_residual(h, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, out_mask,
                                     out, sm, km)
@@ -439,10 +405,7 @@ class TransformerBlock(_BlockBase):
 
     def forward(self, x, mask, pos_embd=None):
         assert pos_embd is None
-        res = self.attn.attend_prenorm((x, x, x), (self.ln1, self.ln1, self.ln1), (mask, mask, mask), tail=self._fused_tail)
-        if len(res) == 2:
-            return res                                       # fused tail: (block output, out_mask)
-        out, out_mask, x_res = res
+        out, out_mask, x_res = self.attn.attend_prenorm((x, x, x), (self.ln1, self.ln1, self.ln1), (mask, mask, mask))
         return self._residual_mlp(x_res, out, out_mask), out_mask
 
 
@@ -469,11 +432,8 @@ class MutilModelTransformerBlock(_BlockBase):
 
     def forward(self, x_q, mask_q, x_k=None, mask_k=None, x_v=None, mask_v=None, pos_embd=None, kv_shift=0):
         assert pos_embd is None
-        res = self.attn.attend_prenorm((x_q, x_k, x_v), (self.lnq, self.lnk, self.lnv), (mask_q, mask_k, mask_v), kv_shift,
-                                       tail=self._fused_tail)
-        if len(res) == 2:
-            return res                                       # fused tail: (block output, out_mask)
-        out, out_mask, x_res = res
+        out, out_mask, x_res = self.attn.attend_prenorm((x_q, x_k, x_v), (self.lnq, self.lnk, self.lnv),
+                                                        (mask_q, mask_k, mask_v), kv_shift)
         return self._residual_mlp(x_res, out, out_mask), out_mask
 
 

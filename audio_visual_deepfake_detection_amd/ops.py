@@ -216,9 +216,7 @@ def _main_grad(t):
 # --------------------------------------------------------------------------------------------
 class Conv1dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, mask, stride, act, pre=None):
-        # pre: the output, already computed by a fused forward launch (block_fused.hip) -- this node only records the
-        # autograd edge and what its backward reads
+    def forward(ctx, x, w, bias, mask, stride, act):
         w0, b0 = w, bias
         x, w, bias, mask = _c(x), _c(w), _c(bias), _c(mask)
         B, Tin, Cin = x.shape
@@ -226,17 +224,13 @@ class Conv1dFn(torch.autograd.Function):
         assert Cin_w == Cin, (w.shape, x.shape)
         assert Tin % stride == 0, "input length must be divisible by stride"   # blocks.py:46
         Tout = (Tin + 2 * (K // 2) - K) // stride + 1
-        if pre is not None:
-            assert act == ACT_NONE and tuple(pre.shape) == (B, Tout, Cout)
-            y, ypre = pre, None
-        else:
-            y = torch.empty((B, Tout, Cout), dtype=x.dtype, device=x.device)
-            need_pre = act != ACT_NONE and any(ctx.needs_input_grad)
-            ypre = torch.empty_like(y) if need_pre else None
-            fl = 2.0 * B * Tout * Cout * Cin * K
-            _timed(_conv_tag("fwd", K, stride, B, Tout, Cout), fl, lambda: check(
-                lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
-                                    K, stride, act, _stream()), "conv1d_fwd"), ("fwd", K, stride, B, Tin, Cin, Cout, 1))
+        y = torch.empty((B, Tout, Cout), dtype=x.dtype, device=x.device)
+        need_pre = act != ACT_NONE and any(ctx.needs_input_grad)
+        ypre = torch.empty_like(y) if need_pre else None
+        fl = 2.0 * B * Tout * Cout * Cin * K
+        _timed(_conv_tag("fwd", K, stride, B, Tout, Cout), fl, lambda: check(
+            lib.avdf_conv1d_fwd(_p(x), _p(w), _p(bias), _p(mask), _p(y), _p(ypre), B, Tin, Cin, Tout, Cout,
+                                K, stride, act, _stream()), "conv1d_fwd"), ("fwd", K, stride, B, Tin, Cin, Cout, 1))
         ctx.save_for_backward(x, w, mask, ypre)
         ctx.cfg = (B, Tin, Cin, Tout, Cout, K, stride, act, bias is not None)
         ctx.main = (_main_grad(w0), _main_grad(b0))
@@ -269,7 +263,7 @@ class Conv1dFn(torch.autograd.Function):
                                                  _ptr_table([mb.view(Cout)]) if has_bias else None,
                                                  B, Tin, Cin, Cout, act, st), "conv1d_bwd_pair"),
                    ("pair", K, stride, B, Tin, Cin, Cout, 1))
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             fl = 2.0 * B * Tout * Cout * Cin * K
@@ -292,7 +286,7 @@ class Conv1dFn(torch.autograd.Function):
                                      "conv1d_bwd_weight"), ("wgrad", K, stride, B, Tin, Cin, Cout, 1))
             if acc:
                 dw = db = None
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None
 
 
 BWD_PAIR = True      # K=1 layers: data + weight gradient in one launch (avdf_conv1d_bwd_pair_grouped) on the engine path
@@ -529,8 +523,7 @@ class Conv1dGroup3Fn(torch.autograd.Function):
     the q / k / v 1x1 projections (blocks.py:1176-1178, 734-736)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, x2, w0, w1, w2, b0, b1, b2, pre=None):
-        # pre: the three outputs already computed by avdf_qkv_fused_fwd (this node then only records the autograd edge)
+    def forward(ctx, x0, x1, x2, w0, w1, w2, b0, b1, b2):
         ws0, bs0 = [w0, w1, w2], [b0, b1, b2]
         xs, ws_, bs = [_c(t) for t in (x0, x1, x2)], [_c(t) for t in ws0], [_c(t) for t in bs0]
         B, T, Cin = xs[0].shape
@@ -538,18 +531,14 @@ class Conv1dGroup3Fn(torch.autograd.Function):
         assert Cin_w == Cin and all(t.shape == xs[0].shape for t in xs) and all(t.shape == ws_[0].shape for t in ws_)
         has_bias = bs[0] is not None
         assert all((b is not None) == has_bias for b in bs)
-        if pre is not None:
-            ys = list(pre)
-            assert K == 1 and all(tuple(t.shape) == (B, T, Cout) for t in ys)
-        else:
-            ys = [torch.empty((B, T, Cout), dtype=torch.float32, device=xs[0].device) for _ in range(3)]
-            for t in xs + ws_ + ([b for b in bs] if has_bias else []):
-                _p(t)
-            fl = 3 * 2.0 * B * T * Cout * Cin * K
-            _timed(_conv_tag("fwd3", K, 1, 3 * B, T, Cout), fl, lambda: check(
-                lib.avdf_conv1d_fwd_grouped(3, _ptr_table(xs), _ptr_table(ws_), _ptr_table(bs) if has_bias else None, None,
-                                            _ptr_table(ys), None, B, T, Cin, T, Cout, K, 1, ACT_NONE, _stream()),
-                "conv1d_fwd_grouped"), ("fwd", K, 1, B, T, Cin, Cout, 3))
+        ys = [torch.empty((B, T, Cout), dtype=torch.float32, device=xs[0].device) for _ in range(3)]
+        for t in xs + ws_ + ([b for b in bs] if has_bias else []):
+            _p(t)
+        fl = 3 * 2.0 * B * T * Cout * Cin * K
+        _timed(_conv_tag("fwd3", K, 1, 3 * B, T, Cout), fl, lambda: check(
+            lib.avdf_conv1d_fwd_grouped(3, _ptr_table(xs), _ptr_table(ws_), _ptr_table(bs) if has_bias else None, None,
+                                        _ptr_table(ys), None, B, T, Cin, T, Cout, K, 1, ACT_NONE, _stream()),
+            "conv1d_fwd_grouped"), ("fwd", K, 1, B, T, Cin, Cout, 3))
         ctx.save_for_backward(*xs, *ws_)
         ctx.cfg = (B, T, Cin, Cout, K, has_bias)
         ctx.main = ([_main_grad(t) for t in ws0], [_main_grad(t) for t in bs0])
@@ -581,7 +570,7 @@ class Conv1dGroup3Fn(torch.autograd.Function):
                                                  _ptr_table([m.view(Cout) for m in mb]) if has_bias else None,
                                                  B, T, Cin, Cout, ACT_NONE, st), "conv1d_bwd_pair"),
                    ("pair", K, 1, B, T, Cin, Cout, 3))
-            return (*dxs, None, None, None, None, None, None, None)
+            return (*dxs, None, None, None, None, None, None)
         if any(ctx.needs_input_grad[0:3]):
             dxs = [torch.empty_like(x) for x in xs]
             _timed(_conv_tag("dgrad3", K, 1, 3 * B, T, Cin), fl, lambda: check(
@@ -603,8 +592,8 @@ class Conv1dGroup3Fn(torch.autograd.Function):
                                                    ACT_NONE, acc, _stream()), "conv1d_bwd_weight_grouped"),
                    ("wgrad", K, 1, B, T, Cin, Cout, 3))
         if acc:
-            return (*dxs, None, None, None, None, None, None, None)
-        return (*dxs, *dws, *(dbs if has_bias else [None] * 3), None)
+            return (*dxs, None, None, None, None, None, None)
+        return (*dxs, *dws, *(dbs if has_bias else [None] * 3))
 
 
 def conv1d_group3(xs, ws, bs):
@@ -796,8 +785,7 @@ class QkvChainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xk, xv, gaq, baq, gak, bak, gav, bav, wq, wk, wv, gbq, bbq, gbk, bbk, gbv, bbv, mask, stride,
-                eps, passthrough=False, xshift=None, pre=None):
-        # pre = (u[3], y[3], sa, sb) already written by avdf_qkv_fused_fwd: this node only records what its backward reads
+                eps, passthrough=False, xshift=None):
         # xshift (optional, per branch): nearest resampling of that branch's input folded into the kernels' row address
         # (> 0: the input has Tin >> s rows and is read as if up-sampled by 2^s; < 0: Tin << -s rows, every 2^-s-th read)
         xshift = tuple(int(v) for v in (xshift or (0, 0, 0)))
@@ -815,18 +803,13 @@ class QkvChainFn(torch.autograd.Function):
             assert xi.shape == (B, (Tin >> sh) if sh > 0 else (Tin << -sh), C), (xi.shape, (B, Tin, C), sh)
         Tout = (Tin - 1) // stride + 1
         dev = xs[0].device
-        if pre is not None:
-            u, y, sa, sb = pre
-        else:
-            u = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
-            y = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
-            sa = torch.empty((3, 2, B * Tin), dtype=torch.float32, device=dev)
-            sb = torch.empty((3, 2, B * Tout), dtype=torch.float32, device=dev)
+        u = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
+        y = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
+        sa = torch.empty((3, 2, B * Tin), dtype=torch.float32, device=dev)
+        sb = torch.empty((3, 2, B * Tout), dtype=torch.float32, device=dev)
         for t in xs + ga + ba + ws_ + gb + bb:
             _p(t)
-        if pre is not None:
-            pass
-        elif any(xshift):
+        if any(xshift):
             check(lib.avdf_chain_fwd_map(_ptr_table(xs), _ptr_table(ga), _ptr_table(ba), _ptr_table(ws_), _ptr_table(gb),
                                          _ptr_table(bb), _p(mask), _ptr_table(u), _ptr_table(y),
                                          _ptr_table([sa[0], sa[1], sa[2]]), _ptr_table([sb[0], sb[1], sb[2]]),
@@ -926,7 +909,7 @@ class QkvChainFn(torch.autograd.Function):
                                            offs, 1 if acc else 0, _stream()), "reduce_segments")
         g = grads
         return (dx[0], dx[1], dx[2], g[0][0], g[1][0], g[0][1], g[1][1], g[0][2], g[1][2], g[2][0], g[2][1], g[2][2],
-                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None, None, None, None)
+                g[3][0], g[4][0], g[3][1], g[4][1], g[3][2], g[4][2], None, None, None, None, None)
 
 
 def qkv_chain(xs, ln_a, dw, ln_b, mask_out, stride, eps=1e-5, passthrough=False, xshift=None):
@@ -984,25 +967,21 @@ class LocalAttnFn(torch.autograd.Function):
     use_time_weight (blocks.py:968-975): a bias on the scores before the softmax, a weight on the probabilities after it."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kvmask, n_head, window, rel_pe=None, time_w=None, pre=None):
-        # pre = (out, probs) already written by avdf_attn_out_fused_fwd
+    def forward(ctx, q, k, v, kvmask, n_head, window, rel_pe=None, time_w=None):
         q, k, v, kvmask = _c(q), _c(k), _c(v), _c(kvmask)
         B, T, C = q.shape
         assert k.shape == q.shape and v.shape == q.shape, "local attention needs equal q/k/v lengths"
         assert T % (2 * (window // 2)) == 0      # blocks.py:1060
         hs = C // n_head
         scale = 1.0 / (hs ** 0.5)
+        out = torch.empty_like(q)
+        need = any(ctx.needs_input_grad)
+        probs = torch.empty((B, T, n_head, window), dtype=q.dtype, device=q.device) if need else None
         rel = None if rel_pe is None else rel_pe.contiguous().view(-1)
         tw = None if time_w is None else time_w.contiguous().view(-1)
         assert (rel is None or rel.numel() == n_head * window) and (tw is None or tw.numel() == n_head * window)
-        if pre is not None:
-            out, probs = pre
-        else:
-            out = torch.empty_like(q)
-            need = any(ctx.needs_input_grad)
-            probs = torch.empty((B, T, n_head, window), dtype=q.dtype, device=q.device) if need else None
-            check(lib.avdf_local_attn_fwd_ex(_p(q), _p(k), _p(v), _p(kvmask), _p(rel), _p(tw), _p(out), _p(probs), B, T, n_head,
-                                             hs, window, scale, _stream()), "local_attn_fwd")
+        check(lib.avdf_local_attn_fwd_ex(_p(q), _p(k), _p(v), _p(kvmask), _p(rel), _p(tw), _p(out), _p(probs), B, T, n_head, hs,
+                                         window, scale, _stream()), "local_attn_fwd")
         ctx.save_for_backward(q, k, v, probs, tw)
         ctx.cfg = (B, T, n_head, hs, window, scale)
         ctx.main = (_main_grad(rel_pe), _main_grad(time_w))
@@ -1032,7 +1011,7 @@ class LocalAttnFn(torch.autograd.Function):
             ws2 = _ws(lib.avdf_masked_colsum_ws(n), q)
             check(lib.avdf_masked_colsum(_p(src), None, _p(dst), _p(ws2), B * T, n, acc, _stream()), "masked_colsum")
             grads[i] = None if acc else dst.view(ctx.shapes[i])
-        return dq, dk, dv, None, None, None, grads[0], grads[1], None
+        return dq, dk, dv, None, None, None, grads[0], grads[1]
 
 
 class GlobalAttnFn(torch.autograd.Function):
@@ -1138,20 +1117,16 @@ class ResidualLnFn(torch.autograd.Function):
     its incoming gradient and LN's are combined in ONE backward kernel (no aten add, no separate LN backward)."""
 
     @staticmethod
-    def forward(ctx, a, ma, r, mr, scale, keep, gamma, beta, eps, pre=None):
-        # pre = (out, h, stats) already written by avdf_attn_out_fused_fwd
+    def forward(ctx, a, ma, r, mr, scale, keep, gamma, beta, eps):
         ctx.main = (_main_grad(scale), _main_grad(gamma), _main_grad(beta))
         ctx.shapes = (scale.shape, gamma.shape, beta.shape)
         a, ma, r, mr, keep = _c(a), _c(ma), _c(r), _c(mr), _c(keep)
         B, T, C = a.shape
         sc, g, b = scale.contiguous().view(-1), gamma.contiguous().view(-1), beta.contiguous().view(-1)
-        if pre is not None:
-            out, h, stats = pre
-        else:
-            out, h = torch.empty_like(a), torch.empty_like(a)
-            stats = torch.empty((2, B * T), dtype=torch.float32, device=a.device)
-            check(lib.avdf_residual_ln_fwd(_p(a), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(g), _p(b), _p(out), _p(h),
-                                           _p(stats[0]), _p(stats[1]), B, T, C, eps, _stream()), "residual_ln_fwd")
+        out, h = torch.empty_like(a), torch.empty_like(a)
+        stats = torch.empty((2, B * T), dtype=torch.float32, device=a.device)
+        check(lib.avdf_residual_ln_fwd(_p(a), _p(ma), _p(r), _p(mr), _p(sc), _p(keep), _p(g), _p(b), _p(out), _p(h),
+                                       _p(stats[0]), _p(stats[1]), B, T, C, eps, _stream()), "residual_ln_fwd")
         ctx.save_for_backward(out, stats, g, ma, r, mr, sc, keep)
         return out, h
 
@@ -1181,101 +1156,13 @@ class ResidualLnFn(torch.autograd.Function):
             # (no float atomics inside the kernel: 128 workgroups x 768 adds onto the same 768 floats)
             _DEFERRED.append((ws, nws // (3 * C), 3 * C, [ds, dg, db], [C, C, C], [[0], [C], [2 * C]]))
         if acc:
-            return da, None, dr, None, None, None, None, None, None, None
+            return da, None, dr, None, None, None, None, None, None
         s0, s1, s2 = ctx.shapes
-        return da, None, dr, None, ds.view(s0), None, dg.view(s1), db.view(s2), None, None
+        return da, None, dr, None, ds.view(s0), None, dg.view(s1), db.view(s2), None
 
 
 def residual_ln(a, ma, r, mr, scale, keep, gamma, beta, eps=1e-5):
     return ResidualLnFn.apply(a, ma, r, mr, scale, keep, gamma, beta, eps)
-
-
-# --------------------------------------------------------------------------------------------
-# row-block fused forward launches of one attention half-block (csrc/block_fused.hip, C = 256).  The backward pass is
-# the per-op one: the fused launch writes exactly the tensors those backward kernels read, and the autograd nodes of
-# the per-op path are recorded around its outputs (`pre=`), so gradients are those of the per-op path by construction.
-# --------------------------------------------------------------------------------------------
-FUSE_BLOCK = _os.environ.get("AVDF_FUSE_BLOCK", "1") != "0"
-
-
-def qkv_fused_ok(C, bias_list):
-    return (FUSE_BLOCK and C == 256 and not (current_gemm_mode() & 1)
-            and (all(b is None for b in bias_list) or all(b is not None for b in bias_list)))
-
-
-def qkv_fused(xs, ln_a, dw, ln_b, proj_w, proj_b, mask_out, stride, eps=1e-5, passthrough=False, xshift=None):
-    """LN_a -> depthwise k3 (stride) * mask -> LN_b -> 1x1 projection of q, k, v in ONE launch -> (q, k, v[, x_q]).
-    Arguments as `qkv_chain` plus the three projection weights [C, C, 1] / biases."""
-    xshift = tuple(int(v) for v in (xshift or (0, 0, 0)))
-    xc = [_c(t) for t in xs]
-    B, Tin, C = xc[0].shape
-    Tout = (Tin - 1) // stride + 1
-    dev = xc[0].device
-    flat = lambda grp: [t.contiguous().view(-1) for t in grp]
-    ga, ba = flat([p[0] for p in ln_a]), flat([p[1] for p in ln_a])
-    gb, bb = flat([p[0] for p in ln_b]), flat([p[1] for p in ln_b])
-    dwf, pw = flat(dw), [_c(w) for w in proj_w]
-    pb = None if proj_b[0] is None else [_c(b) for b in proj_b]
-    mask = _c(mask_out)
-    train = torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or any(w.requires_grad for w in proj_w))
-    u = y = sa = sb = None
-    if train:
-        u = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
-        y = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
-        sa = torch.empty((3, 2, B * Tin), dtype=torch.float32, device=dev)
-        sb = torch.empty((3, 2, B * Tout), dtype=torch.float32, device=dev)
-    qkv = [torch.empty((B, Tout, C), dtype=torch.float32, device=dev) for _ in range(3)]
-    for t in xc + ga + ba + dwf + gb + bb + pw + (pb or []):
-        _p(t)
-    _timed("qkv_fused_fwd", 3 * 2.0 * B * Tout * C * C, lambda: check(
-        lib.avdf_qkv_fused_fwd(_ptr_table(xc), _ptr_table(ga), _ptr_table(ba), _ptr_table(dwf), _ptr_table(gb), _ptr_table(bb),
-                               _ptr_table(pw), _ptr_table(pb) if pb else None, _p(mask),
-                               _ptr_table(u) if train else None, _ptr_table(y) if train else None,
-                               _ptr_table([sa[0], sa[1], sa[2]]) if train else None,
-                               _ptr_table([sb[0], sb[1], sb[2]]) if train else None, _ptr_table(qkv),
-                               (ctypes.c_int * 3)(*xshift), B, Tin, Tout, C, stride, eps, _stream()), "qkv_fused_fwd"))
-    if not train:
-        return (*qkv, xs[0]) if passthrough else tuple(qkv)
-    ys = QkvChainFn.apply(xs[0], xs[1], xs[2], ln_a[0][0], ln_a[0][1], ln_a[1][0], ln_a[1][1], ln_a[2][0], ln_a[2][1],
-                          dw[0], dw[1], dw[2], ln_b[0][0], ln_b[0][1], ln_b[1][0], ln_b[1][1], ln_b[2][0], ln_b[2][1],
-                          mask_out, stride, eps, passthrough, xshift if any(xshift) else None, (u, y, sa, sb))
-    q, k, v = Conv1dGroup3Fn.apply(ys[0], ys[1], ys[2], proj_w[0], proj_w[1], proj_w[2], proj_b[0], proj_b[1], proj_b[2],
-                                   tuple(qkv))
-    return (q, k, v, ys[3]) if passthrough else (q, k, v)
-
-
-def attn_out_fused_ok(C, n_head, window, ln_affine):
-    return bool(FUSE_BLOCK and ln_affine and not (current_gemm_mode() & 1)
-                and lib.avdf_attn_out_fused_supported(int(C), int(n_head), int(window)))
-
-
-def attn_out_fused(q, k, v, mask, n_head, window, rel_pe, time_w, proj_w, proj_b, skip, scale, keep, gamma, beta, eps=1e-5):
-    """Banded attention -> output projection (+bias, *mask) -> skip*mask + scale*keep*proj -> LN2 in ONE launch
-    -> (out, h) = the block's residual stream after the attention half and the MLP's input."""
-    qc, kc, vc, maskc, skipc, keepc = _c(q), _c(k), _c(v), _c(mask), _c(skip), _c(keep)
-    B, T, C = qc.shape
-    assert kc.shape == qc.shape and vc.shape == qc.shape and T % (2 * (window // 2)) == 0      # blocks.py:1060
-    dev = qc.device
-    rel = None if rel_pe is None else rel_pe.contiguous().view(-1)
-    tw = None if time_w is None else time_w.contiguous().view(-1)
-    pw, pb = _c(proj_w), _c(proj_b)
-    sc, g, bt = scale.contiguous().view(-1), gamma.contiguous().view(-1), beta.contiguous().view(-1)
-    train = torch.is_grad_enabled() and (q.requires_grad or skip.requires_grad or proj_w.requires_grad)
-    att = probs = r = stats = None
-    if train:
-        att, r = torch.empty_like(qc), torch.empty_like(qc)
-        probs = torch.empty((B, T, n_head, window), dtype=torch.float32, device=dev)
-        stats = torch.empty((2, B * T), dtype=torch.float32, device=dev)
-    out, h = torch.empty_like(qc), torch.empty_like(qc)
-    _timed("attn_out_fused_fwd", 2.0 * B * T * C * C, lambda: check(
-        lib.avdf_attn_out_fused_fwd(_p(qc), _p(kc), _p(vc), _p(maskc), _p(rel), _p(tw), _p(pw), _p(pb), _p(skipc), _p(sc),
-                                    _p(keepc), _p(g), _p(bt), _p(att), _p(probs), _p(r), _p(stats), _p(out), _p(h), B, T, C,
-                                    n_head, window, eps, _stream()), "attn_out_fused_fwd"))
-    if not train:
-        return out, h
-    a = LocalAttnFn.apply(q, k, v, mask, n_head, window, rel_pe, time_w, (att, probs))
-    pr = Conv1dFn.apply(a, proj_w, proj_b, mask, 1, ACT_NONE, r)
-    return ResidualLnFn.apply(skip, mask, pr, None, scale, keep, gamma, beta, eps, (out, h, stats))
 
 
 class ResampleFn(torch.autograd.Function):

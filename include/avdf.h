@@ -431,33 +431,6 @@ int avdf_chain_bwd_map(const float* const* dy, const float* const* u, const floa
                        const float* const* beta_a, const float* const* w, const float* const* gamma_b,
                        const float* mask, float* const* dx, const float* const* dres, int store_mask, float* ws,
                        const int* xshift, int B, int Tin, int Tout, int C, int stride, void* stream);
-/* ---- row-block fused kernels of one conv-attention block (csrc/block_fused.hip; C = 256) ---------------------------
- * A workgroup owns 32 complete token rows, so LayerNorm, 1x1 projection, bias, mask and residual chain in one launch;
- * depthwise k3 and banded attention read a halo of their INPUT.  One attention half-block
- * (libs/modeling/blocks.py:1152-1224,1307-1313 / 783-876) = two launches.
- *
- * avdf_qkv_fused_fwd: avdf_chain_fwd_map (LN_a -> depthwise k3 stride s * mask -> LN_b of q, k, v) followed by the three
- * 1x1 projections proj[i] = y[i] pw[i]^T + pb[i] (pw[i] = Conv1d weight [C, C, 1] as it lies; pb may be NULL or hold
- * NULLs).  u / y / stats_a / stats_b are the tensors avdf_chain_bwd* and the projections' backward read: pass all four
- * tables (training) or all NULL (inference: nothing but proj is written).  xshift may be NULL.                       */
-int avdf_qkv_fused_fwd(const float* const* x, const float* const* gamma_a, const float* const* beta_a,
-                       const float* const* w, const float* const* gamma_b, const float* const* beta_b,
-                       const float* const* pw, const float* const* pb, const float* mask, float* const* u,
-                       float* const* y, float* const* stats_a, float* const* stats_b, float* const* proj,
-                       const int* xshift, int B, int Tin, int Tout, int C, int stride, float eps, void* stream);
-/* 1 if avdf_attn_out_fused_fwd has a kernel for (C, heads, window): C = 256, heads in {4, 8}, window in {3,5,7,9}. */
-int avdf_attn_out_fused_supported(int C, int H, int window);
-/* avdf_local_attn_fwd_ex -> avdf_conv1d_fwd (output projection, * mask) -> avdf_residual_ln_fwd in one launch:
- *   att = softmax_band(q k^T / sqrt(hs) [+ rel]) [* tw] v;   r = (att pw^T + pb) * mask[row];
- *   out = skip * mask[row] + scale[c] * keep[b] * r;         h = LN(out) * gamma + beta.
- * mask [B, T] is the key mask and the row mask (the fused block path has one mask per level); keep may be NULL.
- * att [B,T,C], probs [B,T,H,window], r [B,T,C], stats [2, B*T] (mean | rstd) are what avdf_local_attn_bwd_ex, the
- * projection's backward and avdf_residual_ln_bwd read: all four (training) or all NULL (inference).                  */
-int avdf_attn_out_fused_fwd(const float* q, const float* k, const float* v, const float* mask, const float* rel,
-                            const float* tw, const float* pw, const float* pb, const float* skip, const float* scale,
-                            const float* keep, const float* gamma, const float* beta, float* att, float* probs, float* r,
-                            float* stats, float* out, float* h, int B, int T, int C, int H, int window, float eps,
-                            void* stream);
 /* dst[s][i] (+)= sum over rows r < nrow and sources j < nsrc[s] of ws[r*row_stride + src_off[s*3+j] + i],
  * i < len[s]; up to 16 segments per launch (host arrays).                                                   */
 int avdf_reduce_segments(const float* ws, int nrow, int row_stride, int nseg, float* const* dst, const int* len,

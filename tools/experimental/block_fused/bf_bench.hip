@@ -1,11 +1,11 @@
 // Isolated timing of the row-block fused kernels (csrc/block_fused.hip) at the shapes of the exp10 pyramid.
-//   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on tools/micro/bf_bench.hip -o tools/micro/bf_bench
-//   run:   tools/micro/bf_bench [B=8] [T=768] [train=1]
+//   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on tools/experimental/block_fused/bf_bench.hip -o tools/experimental/block_fused/bf_bench
+//   run:   tools/experimental/block_fused/bf_bench [B=8] [T=768] [train=1]
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../audio_visual_deepfake_detection_amd/csrc/block_fused.hip"
+#include "block_fused.hip"
 
 void avdf_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 

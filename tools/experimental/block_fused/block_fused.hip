@@ -23,7 +23,7 @@
 // Algorithmic work per token (C = 256): qkv: 3 x 2*C*C = 393 kFLOP, out-projection 131 kFLOP; HBM bytes per token in
 // inference: qkv reads 1-3 KB (x of each distinct input) and writes 3 KB, attn+out reads 3 KB + 1 KB skip and
 // writes 2 KB.  MFMA-bound (fp32): 157.3 TFLOP/s peak.
-#include "common.h"
+#include "../../../audio_visual_deepfake_detection_amd/csrc/common.h"
 
 namespace {
 
