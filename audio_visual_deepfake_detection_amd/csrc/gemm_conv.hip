@@ -1140,11 +1140,15 @@ __global__ __launch_bounds__(64 * WM * WN * KGD, ((!BF3 && WM == 1 && WN == 4 &&
   const int G = gridDim.x, hw = blockIdx.x;
   const int xcd = hw & 7;
   // position in XCD-major order (tilesT < 0: grid order, the A/B switch AVDF_PAIR_XCD=0)
-  const int v = tilesT < 0 ? hw : xcd * (G >> 3) + min(xcd, G & 7) + (hw >> 3);
-  if (tilesT < 0) tilesT = -tilesT;
+  const bool grid_order = tilesT < 0;
+  const int v = grid_order ? hw : xcd * (G >> 3) + min(xcd, G & 7) + (hw >> 3);
+  if (grid_order) tilesT = -tilesT;
   int c = 0;
-  while (c < 7 && v >= (int)(((long)(c + 1) * nW) >> 3) + (int)(((long)(c + 1) * (G - nW)) >> 3)) ++c;
-  const int w0 = (int)(((long)c * nW) >> 3), w1 = (int)(((long)(c + 1) * nW) >> 3), d0 = (int)(((long)c * (G - nW)) >> 3);
+  if (!grid_order)
+    while (c < 7 && v >= (int)(((long)(c + 1) * nW) >> 3) + (int)(((long)(c + 1) * (G - nW)) >> 3)) ++c;
+  // grid order: one chunk = the whole grid (wgrad items first, then dgrad items)
+  const int w0 = grid_order ? 0 : (int)(((long)c * nW) >> 3), w1 = grid_order ? nW : (int)(((long)(c + 1) * nW) >> 3),
+            d0 = grid_order ? 0 : (int)(((long)c * (G - nW)) >> 3);
   const int local = v - (w0 + d0);
   if (local < w1 - w0) {
     const int id = w0 + local;
@@ -1154,7 +1158,8 @@ __global__ __launch_bounds__(64 * WM * WN * KGD, ((!BF3 && WM == 1 && WN == 4 &&
   } else {
     const int id = d0 + local - (w1 - w0);
     const int nprob = (G - nW) / (dgx * dgy);                              // row tile slowest, then problem, then column tile
-    const int by = id % dgy, bz = (id / dgy) % nprob, bx = id / (dgy * nprob);
+    int by = id % dgy, bz = (id / dgy) % nprob, bx = id / (dgy * nprob);
+    if (grid_order) { bx = id % dgx; by = (id / dgx) % dgy; bz = id / (dgx * dgy); }      // the round-3 order
     conv_dgrad_body<1, 1, WM, WN, MI, NI, KC, KGD, false, BF3>(smem, dp, B, T, Cin, T, Cout, act, tilesT, bx, by, bz);
   }
 }
@@ -1798,7 +1803,7 @@ extern "C" int avdf_conv1d_bwd_weight_grouped(int n, const float* const* dy, con
 // dw[i] / dbias[i] with float atomics (the engine's flat-gradient path); dx[i] is overwritten.  g_pair_mode 0 turns
 // the fusion off (two launches, the reference point of tools/gemm_bench.py).
 static int g_pair_mode = [] { const char* e = getenv("AVDF_BWD_PAIR"); return e ? atoi(e) : 1; }();
-static const int g_pair_xcd = [] { const char* e = getenv("AVDF_PAIR_XCD"); return e ? atoi(e) : 1; }();   // 0: grid order (A/B)
+static const int g_pair_xcd = [] { const char* e = getenv("AVDF_PAIR_XCD"); return e ? atoi(e) : 0; }();   // 1: XCD-aware work order (halves the fabric traffic, -0.55 % step throughput: DESIGN.md section 6.2)
 extern "C" int avdf_bwd_pair_mode(int mode) { g_pair_mode = mode; return AVDF_OK; }
 
 extern "C" int avdf_conv1d_bwd_pair_grouped(int n, const float* const* dy, const float* const* w, const float* const* x,

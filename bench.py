@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the eager per-launch timing pass (tools/plan_ab.py)")
+    ap.add_argument("--shape-table", default=None, metavar="PATH",
+                    help="also write the per-(kernel class, GEMM shape) table of the roofline pass (launches, us, TFLOP/s, "
+                         "time above an 80 %%-of-peak launch) to PATH: where the MFMA time of the step goes, shape by shape")
     ap.add_argument("--wgrad-side", action="store_true",
                     help="weight-gradient GEMMs on a second HIP stream (measured slower inside hipGraphs: 558 vs 611 clips/s)")
     ap.add_argument("--branch-streams", action="store_true", help="run the q/k/v chains on three HIP streams")
@@ -433,6 +436,20 @@ def main():
         a[0] += 1
         a[1] += s.elapsed_time(e) * 1e-3
         a[2] += fl
+    if args.shape_table and rank == 0:
+        by_shape = {}
+        for tag, fl, s, e, shape in recs:
+            a = by_shape.setdefault((tag, shape), [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += fl
+        rows = sorted(by_shape.items(), key=lambda kv: -(kv[1][1] - kv[1][2] / (0.8 * peak * 1e12)))
+        with open(args.shape_table, "w") as f:
+            f.write("# kernel class | (kind, K, stride, B, T, Cin, Cout, problems) | launches/step | us/launch | TFLOP/s | "
+                    "us/step above an 80%-of-peak launch\n")
+            for (tag, shape), (n, t, fl) in rows:
+                f.write(f"{tag:24s} {str(shape):44s} {n / nprof:6.1f} {t / n * 1e6:9.1f} {fl / t / 1e12:8.1f} "
+                        f"{(t - fl / (0.8 * peak * 1e12)) / nprof * 1e6:9.1f}\n")
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     tot_t = sum(v[1] for v in agg.values())
     tot_f = sum(v[2] for v in agg.values())
