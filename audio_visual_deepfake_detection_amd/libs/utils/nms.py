@@ -46,6 +46,24 @@ def _soft_nms(segs, scores, cls_idxs, iou_threshold, sigma, min_score, method, m
     return d[:, :2].contiguous(), d[:, 2].contiguous(), cls_idxs[torch.from_numpy(inds[:k].copy())]
 
 
+class NMSop(torch.autograd.Function):
+    """The reference's class name and call form (libs/utils/nms.py:8-35): NMSop.apply(segs, scores, cls_idxs, iou_threshold,
+    min_score, max_num) -> (segs, scores, cls_idxs) of the kept rows in descending-score order."""
+
+    @staticmethod
+    def forward(ctx, segs, scores, cls_idxs, iou_threshold, min_score, max_num):
+        return _hard_nms(segs, scores, cls_idxs, iou_threshold, min_score, max_num)
+
+
+class SoftNMSop(torch.autograd.Function):
+    """libs/utils/nms.py:38-64: SoftNMSop.apply(segs, scores, cls_idxs, iou_threshold, sigma, min_score, method, max_num);
+    method 0 = hard, 1 = linear, 2 = gaussian decay (csrc/nms_cpu.cpp:60-150)."""
+
+    @staticmethod
+    def forward(ctx, segs, scores, cls_idxs, iou_threshold, sigma, min_score, method, max_num):
+        return _soft_nms(segs, scores, cls_idxs, iou_threshold, sigma, min_score, method, max_num)
+
+
 def seg_voting(nms_segs, all_segs, all_scores, iou_threshold, score_offset=1.5):
     """Segment voting (nms.py:67-101): each kept segment becomes the (score * IoU)-weighted mean of all input
     segments with IoU >= iou_threshold.  (`score_offset` is accepted and, as in the reference, has no effect.)"""

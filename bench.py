@@ -95,6 +95,15 @@ def pmc_mfma_util(tag):
         return None
 
 
+def algorithmic_bytes(shape):
+    """HBM bytes one launch of a conv / Linear GEMM has to move (fp32): every operand read once, every result written once.
+    shape = ops._timed's record (kind, K, stride, B, Tin, Cin, Cout, problems); activation pre-images (ypre) not counted."""
+    kind, K, stride, B, Tin, Cin, Cout, n = shape
+    x, y, w = B * Tin * Cin, B * (Tin // stride) * Cout, Cout * Cin * K
+    words = {"fwd": x + w + y, "dgrad": y + w + x, "wgrad": y + x + w, "pair": y + x + w + x + w}[kind]
+    return 4 * n * words
+
+
 def conv_flops_per_clip(cfg_T=768, Cin=3072, D=256):
     """Necessary forward MFMA work per clip (21.58 GF; x3 for fwd+bwd)."""
     return 21.58e9
@@ -431,11 +440,12 @@ def main():
     else:
         eng.graph = graphs
     agg = {}
-    for tag, fl, s, e, _shape in recs:
-        a = agg.setdefault(tag, [0, 0.0, 0.0])
+    for tag, fl, s, e, shape in recs:
+        a = agg.setdefault(tag, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += s.elapsed_time(e) * 1e-3
         a[2] += fl
+        a[3] += algorithmic_bytes(shape) if shape is not None else 0.0
     if args.shape_table and rank == 0:
         by_shape = {}
         for tag, fl, s, e, shape in recs:
@@ -453,13 +463,14 @@ def main():
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     tot_t = sum(v[1] for v in agg.values())
     tot_f = sum(v[2] for v in agg.values())
-    tag, (cnt, tsec, fl) = dom
+    tag, (cnt, tsec, fl, abytes) = dom
     ach = fl / tsec / 1e12
     roof = {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(peak, 1),
             "peak_note": ("bf16 dense MFMA peak / 3 (three bf16 MFMAs per product in bf16x3 mode)" if bf3 else
                           "f32-input MFMA dense peak (the arithmetic the path computes in)"),
             "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": pmc_traffic(tag) if args.mode == "train" else None,
+            "algorithmic_bytes_per_launch": round(abytes / cnt),
             "mfma_util": pmc_mfma_util(tag) if args.mode == "train" else None,
             **({"frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)} if bf3 else {}),
             "launches_per_step": cnt // nprof, "avg_launch_us": round(tsec / cnt * 1e6, 2),
@@ -469,6 +480,8 @@ def main():
             "per_kernel": {k: {"n": v[0] // nprof, "ms_per_step": round(v[1] / nprof * 1e3, 3),
                                "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in sorted(agg.items())}}
 
+    if roof.get("traffic"):
+        roof["traffic"]["over_algorithmic"] = round(roof["traffic"]["bytes_per_launch"] / max(roof["algorithmic_bytes_per_launch"], 1), 2)
     losses = eng.losses() if args.mode == "train" else None          # a collective under DP: every rank calls it
     if rank == 0:
         line = {

@@ -116,3 +116,27 @@ def test_batched_nms_soft_and_multiclass_branches_match_reference(golden_dir):
         o2 = np.lexsort((rs[:, 0], rl, -np.round(rc, 5)))
         assert np.allclose(s.numpy()[o1], rs[o2], atol=1e-3), (i, soft, multi)
         assert np.array_equal(l.numpy()[o1], rl[o2]), (i, soft, multi)
+
+
+def test_reference_named_nms_entry_points(golden_dir):
+    """The reference's names (libs/utils/nms.py:5,8,38): an importable `nms_1d_cpu` with nms / softnms, and the NMSop /
+    SoftNMSop autograd-Function classes, against the reference extension's own outputs (tests/golden/nms.npz)."""
+    import numpy as np
+    import torch
+    from audio_visual_deepfake_detection_amd.libs.utils import nms_1d_cpu
+    from audio_visual_deepfake_detection_amd.libs.utils.nms import NMSop, SoftNMSop
+    g = np.load(os.path.join(golden_dir, "nms.npz"))
+    for i in range(int(g["n_cases"])):
+        segs, sc = torch.from_numpy(g[f"segs{i}"]).reshape(-1, 2), torch.from_numpy(g[f"scores{i}"])
+        inds = nms_1d_cpu.nms(segs, sc, iou_threshold=0.1)
+        assert inds.dtype == torch.int64 and sorted(inds.tolist()) == sorted(g[f"keep{i}"].tolist())
+        cls = torch.zeros(sc.shape[0], dtype=torch.int64)
+        s, c, l = NMSop.apply(segs, sc, cls, 0.1, 0.0, 3)
+        assert s.shape[0] == min(3, inds.shape[0]) and torch.equal(c, sc[inds[:3]]) and torch.equal(s, segs[inds[:3]])
+        # method 0 of the soft kernel IS hard suppression (suppressed scores become 0 and fall below min_score): same kept set
+        dets = torch.zeros((sc.shape[0], 3))
+        si = nms_1d_cpu.softnms(segs, sc, dets, iou_threshold=0.1, sigma=0.5, min_score=1e-9, method=0)
+        assert sorted(si.tolist()) == sorted(inds.tolist())
+        assert torch.equal(dets[:si.shape[0], 2], sc[si]) and torch.equal(dets[:si.shape[0], :2], segs[si])
+        s2, c2, l2 = SoftNMSop.apply(segs, sc, cls, 0.1, 0.5, 0.001, 2, 100)
+        assert s2.shape[0] == c2.shape[0] == l2.shape[0] and (c2.shape[0] == 0 or float(c2.max()) <= float(sc.max()) + 1e-6)

@@ -154,3 +154,24 @@ def test_sharded_inference_runner_equals_clip_by_clip_plugin_path(tmp_path):
         a, b = np.asarray(g["segments"]).reshape(-1, 2), ref["segments"].numpy()
         assert np.allclose(a[np.lexsort(a.T)], b[np.lexsort(b.T)], atol=1e-3)
         assert abs(g["video_cls"][0] - float(ref["video_cls"][0])) < 1e-4
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_reports_data_parallel():
+    """The driver's command form, `python bench.py --gpus 2 ...` with NO rendezvous in the environment, on this one-GPU box:
+    bench.py starts the two ranks itself (round-3 verdict: it used to run one process silently); with
+    AVDF_DIST_BACKEND=gloo the ranks share the GPU and the collectives go through the host -- the measured
+    configuration is one rank per GPU over RCCL, this pins the launch + the N-rank line (n_gpus, global batch,
+    data_parallel object, losses from every rank)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AVDF_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--batch", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2"
+    dpo = line["data_parallel"]
+    assert dpo["grad_bytes"] > 100e6 and len(dpo["buckets_mb"]) >= 2 and dpo["ms_per_step_overlapped"] > 0
+    assert np.isfinite(line["losses"]["final_loss"]) and line["value"] > 0
+    assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
