@@ -541,13 +541,25 @@ __device__ __forceinline__ void conv_dgrad_body(
   constexpr int KCG = KC / KG;
   static_assert(!BF3 || KCG % 16 == 0, "bf16x3 needs 16-deep k-steps per K-group");
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // PAR (k = 3, stride 2; round 4): an output row t' of a stride-2 data gradient sees ONE tap when t' is even (k = 1) and
+  // TWO when it is odd (k = 0, 2).  With consecutive rows on the 32 lanes of an accumulator tile, every MFMA of every tap
+  // ran with half of its rows multiplying zeros: 2x the matrix work (conv_dgrad_k3s2 sat at 34 TFLOP/s algorithmic).  Here
+  // the 32-row sub-tiles of a workgroup take rows of ONE parity (sub-tile 2j: rows 64j + 2i, sub-tile 2j+1: rows 64j + 2i + 1),
+  // so a (sub-tile, tap) pair is either all valid or skipped by a scalar branch.  Even sub-tiles then have one tap of work
+  // and odd ones two: with two row sub-tiles per workgroup (WM = 2, MI = 1) the parity a wave works on alternates with its
+  // K-group, so that the four waves of a SIMD (the four K-groups of one (wm, wn)) carry 2 x 1 + 2 x 2 taps, the same on
+  // every SIMD; every (sub-tile, K-group) pair is still covered exactly once, and the K-group fold is by tile row as before.
+  constexpr bool PAR = (KS == 3) && (S == 2) && (BM % 64 == 0);
+  constexpr bool PSWZ = PAR && (WM == 2) && (MI == 1) && (KG % 2 == 0);
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wid / WPG, w4 = wid % WPG;
-  const int wm = w4 / WN, wn = w4 % WN;
+  const int wm = PSWZ ? ((w4 / WN) ^ (kg & 1)) : (w4 / WN), wn = w4 % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int b = bx / tilesT, tp0 = (bx % tilesT) * BM;
   const int c0 = by * BN;
   const int tA0 = floordiv(tp0 + P - (KS - 1), S);
+  // tile row rho (0 .. BM-1, sub-tile = rho / 32) -> output row offset inside the tile
+  auto tile_row = [](int rho) { return PAR ? ((rho & ~63) + ((rho & 31) << 1) + ((rho >> 5) & 1)) : rho; };
 
   floatx16 acc[MI * NI];
 #pragma unroll
@@ -557,15 +569,17 @@ __device__ __forceinline__ void conv_dgrad_body(
 
   // per (mi, k): LDS row of the dy tile this lane's output row reads, or -1 (stride-2 parity miss)
   int arow[MI][KS];
+  bool use[MI][KS];                      // PAR: wave-uniform -- does this (sub-tile, tap) pair contribute at all?
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      const int num = tp0 + (wm * MI + mi) * 32 + li + P - k;
+      const int num = tp0 + tile_row((wm * MI + mi) * 32 + li) + P - k;
       int r = -1;
       if (S == 1) r = num - tA0;
       else if (((num % S) + S) % S == 0) r = floordiv(num, S) - tA0;
       arow[mi][k] = (r >= 0 && r < RA) ? r : -1;
+      use[mi][k] = PAR ? ((((wm * MI + mi) & 1) == 0) == (k == 1)) : true;
     }
 
   F4Buf<NA> ra;
@@ -696,7 +710,8 @@ __device__ __forceinline__ void conv_dgrad_body(
             bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
           }
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int mi = 0; mi < MI; ++mi) {
+            if (!use[mi][k]) continue;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               floatx16 c_ = acc[mi * NI + ni];
@@ -705,6 +720,7 @@ __device__ __forceinline__ void conv_dgrad_body(
               c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], c_, 0, 0, 0);
               acc[mi * NI + ni] = c_;
             }
+          }
         }
       }
     } else if constexpr (VECA) {
@@ -736,6 +752,10 @@ __device__ __forceinline__ void conv_dgrad_body(
     const float* Bg = smem + coff + AS + kg * KCG * LDB;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
+      bool any = false;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) any = any || use[mi][k];
+      if (!any) continue;                                   // scalar branch: no sub-tile of this wave sees tap k
 #pragma unroll
       for (int nn = 0; nn < KCG; nn += 2) {
         float a[MI], bv[NI];
@@ -748,10 +768,12 @@ __device__ __forceinline__ void conv_dgrad_body(
         for (int ni = 0; ni < NI; ++ni)
           bv[ni] = Bg[(nn + lh) * LDB + ((wn * NI + ni) * 32 + li) * KS + k];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
+          if (!use[mi][k]) continue;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[mi * NI + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi * NI + ni], 0, 0, 0);
+        }
       }
     }
     }
@@ -771,7 +793,7 @@ __device__ __forceinline__ void conv_dgrad_body(
   const bool vec = ((Cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(xpre) & 15) == 0);
   tile_epilogue<BM, BN, KG, WN, MI, NI>(acc, smem, kg, wm, wn, li, lh, tid, [&](int row_, int cc, float4 v) {
-    const int tp = tp0 + row_, c = c0 + cc;
+    const int tp = tp0 + tile_row(row_), c = c0 + cc;
     if (tp >= Tin || c >= Cin) return;
     const size_t off = ((size_t)b * Tin + tp) * Cin + c;
     float* o = dx + off;

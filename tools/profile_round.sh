@@ -15,8 +15,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
 STATS=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
-# steps in the trace = calls of the optimiser kernel (one per step: warm-up, capture warm-ups, timed and roofline passes alike)
-NSTEP=$(python3 -c "import csv,sys; print(max([int(r['Calls']) for r in csv.DictReader(open(sys.argv[1])) if 'adamw_ema_seg_kernel' in r['Name']] or [1]))" $STATS)
+# forward + backward passes in the trace = calls of the optimiser kernel (one per bench step: warm-up, timed and roofline
+# passes) + 3 (TrainStep's probe step and the two capture warm-ups run the whole step except the optimiser).  Exact
+# per-step launch counts come from tools/launch_count.sh (difference of two traces).
+NSTEP=$(python3 -c "import csv,sys; print(3 + max([int(r['Calls']) for r in csv.DictReader(open(sys.argv[1])) if 'adamw_ema_seg_kernel' in r['Name']] or [1]))" $STATS)
 python3 tools/kstats.py $STATS $NSTEP 60 > $OUT/kernel_stats.md
 python3 tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
 python3 tools/pmc_mfma.py $OUT/mfma $STATS $OUT/pmc_mfma_util.json > $OUT/pmc_mfma_util.txt
