@@ -451,6 +451,125 @@ __global__ __launch_bounds__(256) void global_attn_bwd_kv_kernel(
   dv[(b * Tk + tk) * C + h * hs + lane] = av;     // masked keys have probs == 0 -> dv == 0
 }
 
+
+// ---- Tk <= 64 (the top pyramid level of the shipped configs: 24 keys per clip): key / value rows in REGISTERS ------------------
+// The general kernels above walk the head dimension with one strided 4-byte gather per step (lane = key, stride = a
+// token row): 64 dependent L2 round trips, 20-23 us per launch for 3 MB (profiles/r04_g_hbm_kernels.md).  Here a lane
+// loads its key's (value's) whole head row with 16-byte loads that are all in flight at once, the dot products run on
+// registers against lane-broadcast query elements, and the row-parallel passes (out = P V, dq = dS K) fetch eight
+// coalesced rows at a time.
+__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+__global__ __launch_bounds__(256) void global_attn_fwd_small_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ kvmask, float* __restrict__ out, float* __restrict__ probs,
+    int B, int Tq, int Tk, int H, int hs, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * H * Tq) return;
+  const int tq = (int)(g % Tq);
+  const int h = (int)((g / Tq) % H);
+  const long b = g / ((long)Tq * H);
+  const int C = H * hs;
+  const float* krow = k + (b * Tk + (lane < Tk ? lane : 0)) * C + h * hs;
+  float4 kr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) kr[i] = (lane < Tk && 4 * i < hs) ? ld4a(krow + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float qd = lane < hs ? q[(b * Tq + tq) * C + h * hs + lane] * scale : 0.f;
+  const float km = lane < Tk ? kvmask[b * Tk + lane] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += __shfl(qd, 4 * i + j, 64) * f4c(kr[i], j);      // lanes >= hs hold qd = 0
+  if (lane >= Tk || km == 0.f) s = -INFINITY;
+  const float m = wave_max(s);
+  s = __expf(s - m);
+  const float p = s / wave_sum(s);
+  if (probs && lane < Tk) probs[((b * H + h) * Tq + tq) * Tk + lane] = p;
+  float o = 0.f;
+  const float* vcol = v + b * Tk * C + h * hs + (lane < hs ? lane : 0);
+  for (int k0 = 0; k0 < Tk; k0 += 8) {
+    float vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[j] = (k0 + j < Tk) ? vcol[(long)(k0 + j) * C] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o += __shfl(p, (k0 + j) & 63, 64) * vv[j];             // p == 0 beyond Tk and on masked keys
+  }
+  if (lane < hs) out[(b * Tq + tq) * C + h * hs + lane] = o;
+}
+
+__global__ __launch_bounds__(256) void global_attn_bwd_q_small_kernel(
+    const float* __restrict__ dout, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ probs, float* __restrict__ dq, float* __restrict__ dS,
+    int B, int Tq, int Tk, int H, int hs, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * H * Tq) return;
+  const int tq = (int)(g % Tq);
+  const int h = (int)((g / Tq) % H);
+  const long b = g / ((long)Tq * H);
+  const int C = H * hs;
+  const float* vrow = v + (b * Tk + (lane < Tk ? lane : 0)) * C + h * hs;
+  float4 vr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) vr[i] = (lane < Tk && 4 * i < hs) ? ld4a(vrow + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float go = lane < hs ? dout[(b * Tq + tq) * C + h * hs + lane] : 0.f;
+  const float p = lane < Tk ? probs[((b * H + h) * Tq + tq) * Tk + lane] : 0.f;           // 0 on masked keys
+  float dp = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dp += __shfl(go, 4 * i + j, 64) * f4c(vr[i], j);
+  const float dot = wave_sum(p * dp);
+  const float ds = p * (dp - dot);
+  if (lane < Tk) dS[((b * H + h) * Tq + tq) * Tk + lane] = ds;
+  float acc = 0.f;
+  const float* kcol = k + b * Tk * C + h * hs + (lane < hs ? lane : 0);
+  for (int k0 = 0; k0 < Tk; k0 += 8) {
+    float kv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kv[j] = (k0 + j < Tk) ? kcol[(long)(k0 + j) * C] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += __shfl(ds, (k0 + j) & 63, 64) * kv[j];
+  }
+  if (lane < hs) dq[(b * Tq + tq) * C + h * hs + lane] = acc * scale;
+}
+
+// one wave per (b, h, tk), eight query rows in flight
+__global__ __launch_bounds__(256) void global_attn_bwd_kv_small_kernel(
+    const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ probs,
+    const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv,
+    int B, int Tq, int Tk, int H, int hs, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= (long)B * H * Tk) return;
+  const int tk = (int)(g % Tk);
+  const int h = (int)((g / Tk) % H);
+  const long b = g / ((long)Tk * H);
+  const int C = H * hs;
+  if (lane >= hs) return;
+  float ak = 0.f, av = 0.f;
+  const float* qcol = q + b * Tq * C + h * hs + lane;
+  const float* gcol = dout + b * Tq * C + h * hs + lane;
+  const long pbase = ((b * H + h) * Tq) * (long)Tk + tk;
+  for (int t0 = 0; t0 < Tq; t0 += 8) {
+    float qv[8], gv[8], sv[8], pv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool on = t0 + j < Tq;
+      qv[j] = on ? qcol[(long)(t0 + j) * C] : 0.f;
+      gv[j] = on ? gcol[(long)(t0 + j) * C] : 0.f;
+      sv[j] = on ? dS[pbase + (long)(t0 + j) * Tk] : 0.f;
+      pv[j] = on ? probs[pbase + (long)(t0 + j) * Tk] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ak += sv[j] * qv[j]; av += pv[j] * gv[j]; }
+  }
+  dk[(b * Tk + tk) * C + h * hs + lane] = ak * scale;
+  dv[(b * Tk + tk) * C + h * hs + lane] = av;     // masked keys have probs == 0 -> dv == 0
+}
+
 }  // namespace
 
 #define DISPATCH_W(W_, CALL)             \
@@ -555,8 +674,13 @@ extern "C" int avdf_global_attn_fwd(const float* q, const float* k, const float*
   AVDF_REQUIRE(B > 0 && Tq > 0 && Tk > 0 && Tk <= 64 * kGMaxSlots && H > 0 && hs > 0 && hs <= 64,
                "global_attn_fwd: bad dims (Tk=%d <= %d, hs=%d <= 64)", Tk, 64 * kGMaxSlots, hs);
   const long waves = (long)B * H * Tq;
-  hipLaunchKernelGGL(global_attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     q, k, v, kvmask, out, probs, B, Tq, Tk, H, hs, scale);
+  const bool small = Tk <= 64 && hs % 4 == 0 && (H * hs) % 4 == 0 && (((uintptr_t)k | (uintptr_t)v) & 15) == 0;
+  if (small)
+    hipLaunchKernelGGL(global_attn_fwd_small_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       q, k, v, kvmask, out, probs, B, Tq, Tk, H, hs, scale);
+  else
+    hipLaunchKernelGGL(global_attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       q, k, v, kvmask, out, probs, B, Tq, Tk, H, hs, scale);
   AVDF_CHECK_LAUNCH("global_attn_fwd");
   return AVDF_OK;
 }
@@ -571,10 +695,18 @@ extern "C" int avdf_global_attn_bwd(const float* dout, const float* q, const flo
   AVDF_REQUIRE(B > 0 && Tq > 0 && Tk > 0 && Tk <= 64 * kGMaxSlots && H > 0 && hs > 0 && hs <= 64, "global_attn_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
   const long wq = (long)B * H * Tq, wk = (long)B * H * Tk;
-  hipLaunchKernelGGL(global_attn_bwd_q_kernel, dim3((unsigned)((wq + 3) / 4)), dim3(256), 0, st,
-                     dout, k, v, probs, dq, ws, B, Tq, Tk, H, hs, scale);
-  hipLaunchKernelGGL(global_attn_bwd_kv_kernel, dim3((unsigned)((wk + 3) / 4)), dim3(256), 0, st,
-                     dout, q, probs, ws, dk, dv, B, Tq, Tk, H, hs, scale);
+  const bool small = Tk <= 64 && hs % 4 == 0 && (H * hs) % 4 == 0 && (((uintptr_t)k | (uintptr_t)v) & 15) == 0;
+  if (small) {
+    hipLaunchKernelGGL(global_attn_bwd_q_small_kernel, dim3((unsigned)((wq + 3) / 4)), dim3(256), 0, st,
+                       dout, k, v, probs, dq, ws, B, Tq, Tk, H, hs, scale);
+    hipLaunchKernelGGL(global_attn_bwd_kv_small_kernel, dim3((unsigned)((wk + 3) / 4)), dim3(256), 0, st,
+                       dout, q, probs, ws, dk, dv, B, Tq, Tk, H, hs, scale);
+  } else {
+    hipLaunchKernelGGL(global_attn_bwd_q_kernel, dim3((unsigned)((wq + 3) / 4)), dim3(256), 0, st,
+                       dout, k, v, probs, dq, ws, B, Tq, Tk, H, hs, scale);
+    hipLaunchKernelGGL(global_attn_bwd_kv_kernel, dim3((unsigned)((wk + 3) / 4)), dim3(256), 0, st,
+                       dout, q, probs, ws, dk, dv, B, Tq, Tk, H, hs, scale);
+  }
   AVDF_CHECK_LAUNCH("global_attn_bwd");
   return AVDF_OK;
 }

@@ -599,7 +599,7 @@ extern "C" int avdf_reduce_segments(const float* ws, int nrow, int row_stride, i
 
 // njobs accumulating reduce_segments jobs in ceil(njobs / 10) launches.  Job j: workspace ws[j] of nrow[j] rows x stride[j]
 // floats, nseg[j] segments; the segment tables of all jobs are concatenated: dst / len / nsrc one entry per segment,
-// src_off three.  Every destination is ADDED to (float atomics; the rows of a job are split four ways over the grid).
+// src_off three.  Every destination is ADDED to (float atomics; AVDF_SEGFOLD_Y row slices per job, default 1).
 extern "C" int avdf_reduce_segments_batched(int njobs, const float* const* ws, const int* nrow, const int* stride, const int* nseg,
                                             float* const* dst, const int* len, const int* nsrc, const int* src_off, void* stream) {
   AVDF_REQUIRE(njobs > 0 && ws && nrow && stride && nseg && dst && len && nsrc && src_off, "reduce_segments_batched: bad args");
@@ -633,7 +633,11 @@ extern "C" int avdf_reduce_segments_batched(int njobs, const float* const* ws, c
       bt.cb_first[q + 1] = bt.cb_first[q] + cdiv(first, 64);
     }
     for (int q = bt.njobs; q < kBatchJobs; ++q) bt.cb_first[q + 1] = bt.cb_first[bt.njobs];
-    hipLaunchKernelGGL(reduce_segments_batch_kernel, dim3(bt.cb_first[bt.njobs], 4), dim3(1024), 0, (hipStream_t)stream, bt);
+    // rows of a job in ONE slice by default (round 4: 853.5 vs 851.4 clips/s for four slices over two alternations -- the
+    // batched launches are already 800+ column blocks -- and a job's partial rows are then summed in a fixed order; the
+    // destinations are still added to atomically: several launches of a phase may meet in one parameter gradient)
+    static const int ysplit = [] { const char* e = getenv("AVDF_SEGFOLD_Y"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+    hipLaunchKernelGGL(reduce_segments_batch_kernel, dim3(bt.cb_first[bt.njobs], ysplit), dim3(1024), 0, (hipStream_t)stream, bt);
     AVDF_CHECK_LAUNCH("reduce_segments_batched");
   }
   return AVDF_OK;

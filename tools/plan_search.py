@@ -28,7 +28,8 @@ def pair_cands(splits=(4, 8, 16)):
 
 
 def tile_cands():
-    return [(t, kg) for t in TILES if t != 5 for kg in (1, 2, 4) if kg <= MAXKG[t]]
+    """data-gradient plans: (tile, K-groups [+ 8: double-buffered operand tiles])"""
+    return [(t, kg + 8 * db) for t in TILES if t != 5 for kg in (1, 2, 4) if kg <= MAXKG[t] for db in (0, 1)]
 
 
 def wgrad_cands():
