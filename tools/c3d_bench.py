@@ -19,7 +19,10 @@ for trim in (True, False):
     dt = (time.perf_counter() - t0) / n
     fl = 1.77e12 * (512 + (264 if trim else 512)) / 512
     print(f"trim_tail={trim}: {dt*1e3:.1f} ms per 768-frame clip, {fl/dt/1e12:.1f} TFLOP/s, {1/dt:.2f} clips/s", flush=True)
-# per-layer timing on one 512-frame chunk
+# per-layer timing on one 512-frame chunk (AVDF_C3D_BF3=1: split-bf16 operands for the Cin >= 16 layers)
+bf3 = int(os.environ.get("AVDF_C3D_BF3", "0"))
+check(lib.avdf_conv3d_mode(bf3), "conv3d_mode")
+print(f"per layer, {'split-bf16' if bf3 else 'exact fp32'}:")
 st = torch.cuda.current_stream().cuda_stream
 T = 512
 shapes = [(4, 64, 96), (64, 64, 96), (64, 96, 32), (96, 96, 32), (96, 128, 16), (128, 128, 16), (128, 128, 8), (128, 128, 4)]
