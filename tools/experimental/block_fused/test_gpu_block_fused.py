@@ -3,12 +3,19 @@ avdf_attn_out_fused_fwd) against a float64 torch statement of the reference bloc
 (libs/modeling/blocks.py:1152-1224 attention, 1307-1313 / 866-872 pre-norms, residual, LN2): forward values, every
 input / parameter gradient (the backward is the per-op one, fed by the tensors the fused launches save), the
 accumulate-into-main_grad engine path, inference (nothing but the outputs is written), strides, shared / distinct
-inputs and the folded nearest resampling of the cross-level blocks."""
+inputs and the folded nearest resampling of the cross-level blocks.
+
+Runs against a tree with `integration.patch` applied and the library rebuilt (see README.md here):
+    python -m pytest tools/experimental/block_fused/test_gpu_block_fused.py"""
 import math
+import os
+import sys
 
 import pytest
 import torch
 import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # repo root
 
 pytestmark = pytest.mark.gpu
 

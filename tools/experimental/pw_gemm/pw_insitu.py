@@ -1,9 +1,9 @@
-"""In-situ A/B of the pipelined pointwise GEMM core (csrc/pw_gemm.hip) against the table plans: for each forward K = 1
+"""In-situ A/B of the pipelined pointwise GEMM core (tools/experimental/pw_gemm/pw_gemm.hip; library built with AVDF_PW_EXPERIMENTAL=1) against the table plans: for each forward K = 1
 shape of the exp10 step, re-capture the training step with the shape's plan row replaced by a pw configuration
-(tile code 8 + cfg, workgroups per CU) and time the whole step.   python tools/pw_insitu.py   (GPU box)"""
+(tile code 8 + cfg, workgroups per CU) and time the whole step.   python tools/experimental/pw_gemm/pw_insitu.py   (GPU box)"""
 import ctypes, json, os, sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import tools.plan_search as ps
 import torch

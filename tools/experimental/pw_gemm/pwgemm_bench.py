@@ -7,7 +7,7 @@ back-to-back launches, L2-warm).
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from audio_visual_deepfake_detection_amd._lib import lib, check
 from audio_visual_deepfake_detection_amd._lib import LIB_PATH
