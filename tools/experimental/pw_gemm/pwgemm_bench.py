@@ -99,11 +99,7 @@ def fwd_case(name, M, Cin, Cout, nprob, act, has_mask, residual, quick):
             if residual:
                 err = max(err, float((out[0].double().cpu() - ref_out).abs().max()) / float(ref_out.abs().max()))
             if err >= 2e-5:
-<<<<<<< Updated upstream:tools/experimental/pw_gemm/pwgemm_bench.py
                 line += f" c{cfg}w{stages} WRONG({err:.1e})"
-=======
-                line += f" c{cfg}s{stages} WRONG({err:.1e})"
->>>>>>> Stashed changes:tools/pwgemm_bench.py
                 continue
             t = timeit(launch)
             if t < best[0]:
