@@ -7,6 +7,12 @@ cannot be resolved, importing this module raises.
 import ctypes
 import os
 
+# torch FIRST: PyTorch-ROCm ships its own libamdhip64 (torch/lib) while libavdf_hip.so is linked against the system one
+# (/opt/rocm/lib).  Whichever is mapped first serves both (same SONAME) -- but only torch's copy is the runtime that owns the
+# devices torch hands us pointers from.  Loading this library before torch left the process with a HIP runtime that
+# reports "no ROCm-capable device" at the first kernel launch (seen on the GPU box: build() then smoke() in one process).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVDF_LIB_PATH") or os.path.join(_HERE, "libavdf_hip.so")     # AVDF_LIB_PATH: A/B builds (tools)
 

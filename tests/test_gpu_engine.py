@@ -396,3 +396,23 @@ def test_state_dict_resume_is_bit_exact_and_loads_into_torch_adamw(use_graph):
         c.step()
     torch.cuda.synchronize()
     assert torch.equal(c.flat_p, want_p) and torch.equal(c.exp_avg_sq, want_v)
+
+
+def test_package_imported_before_torch_still_launches_kernels():
+    """`import audio_visual_deepfake_detection_amd` as the FIRST import of a process (no torch yet -- what
+    __graft_entry__.build() does before smoke()): the library must end up on the HIP runtime torch uses.  Without the
+    import-order guard in _lib.py the first launch failed with "no ROCm-capable device is detected"."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import audio_visual_deepfake_detection_amd as P\n"
+            "from audio_visual_deepfake_detection_amd import ops\n"
+            "import torch\n"
+            "x = torch.arange(2 * 8 * 16, dtype=torch.float32, device='cuda:0').view(2, 8, 16)\n"
+            "y = ops.transpose_last2(x)\n"
+            "assert torch.equal(y, x.transpose(1, 2).contiguous())\n"
+            "print('ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
